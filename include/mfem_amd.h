@@ -1,0 +1,229 @@
+/* mfem_amd.h -- C ABI of the MI355X-native partial-assembly (AssemblyLevel::PARTIAL)
+ * operator-apply + Jacobi-PCG path of MFEM (H1, hexahedra, scalar fields).
+ *
+ * This is the drop-in boundary: every entry point replaces one reference function (cited
+ * as file:line relative to the MFEM source root) and is what an MFEM-side binding would
+ * call from the corresponding C++ virtual / dispatch-table slot.
+ *
+ * Conventions
+ *  - Unless marked HOST, pointers are device pointers (hipMalloc'ed, or
+ *    Vector::Read()/Write()/ReadWrite() pointers of an MFEM build with the HIP backend).
+ *  - B, G (the tiny 1D DofToQuad tables) are HOST pointers (Array::HostRead()): they are
+ *    passed to the kernels by value (kernel-argument segment -> scalar registers).
+ *    Layout is MFEM's DofToQuad::TENSOR layout: B[q + Q1D*d], G[q + Q1D*d]
+ *    (fem/fe/fe_base.cpp:2622-2673).  W (quadrature weights, Q1D^3 doubles,
+ *    W[qx + Q1D*(qy + Q1D*qz)], fem/intrules.cpp:56-84) is a DEVICE pointer.
+ *  - Sizes that can exceed 2^31 are int64_t (the reference uses 32-bit int and cannot hold
+ *    BP3 at 1e8 dofs, linalg/dtensor.hpp:32).  Index arrays are int32 like the reference's.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream, as the reference
+ *    launches, general/forall.hpp:689-718).  All entry points are asynchronous on `stream`
+ *    and never allocate, free or synchronise (safe under HIP graph capture), except where
+ *    noted.
+ *  - Return value: 0 on success, non-zero on error; mfem_amd_last_error() gives the
+ *    message.  The C++ layer turns non-zero into abort-with-message, MFEM's convention
+ *    (general/error.cpp, MFEM_VERIFY / MFEM_GPU_CHECK general/hip.hpp:32-39).
+ *  - Limits: 2 <= D1D <= 10, D1D*Q1D <= 140, Q1D <= 14 (MFEM's HIP limits are
+ *    MAX_D1D = MAX_Q1D = 10, general/forall.hpp:58-61).  Violations return an error, like
+ *    MFEM_VERIFY(D1D <= MAX_D1D) (fem/integ/bilininteg_diffusion_kernels.hpp:1005-1006).
+ */
+#ifndef MFEM_AMD_H
+#define MFEM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- runtime -------------------------------------------------------------------- */
+
+/* Select the HIP device for the calling thread and warm the library up.
+ * Counterpart: Device::Configure("hip") (general/device.hpp:224). */
+int mfem_amd_init(int device);
+/* Last error message of the calling thread (never NULL). */
+const char *mfem_amd_last_error(void);
+/* Non-zero: report on stderr the first use of a non-specialised (fallback) kernel, like
+ * MFEM_REPORT_KERNELS (fem/kernel_reporter.hpp:54-98). Also enabled by that env var. */
+void mfem_amd_report_kernels(int on);
+/* 1 if (D1D,Q1D) has a compile-time specialised apply kernel, else 0 (the dispatch-table
+ * query, fem/kernel_dispatch.hpp:166-181).  kind: 0 = mass, 1 = diffusion. */
+int mfem_amd_has_specialization(int kind, int D1D, int Q1D);
+
+/* ---- ElementRestriction (fem/restriction.cpp) ------------------------------------ */
+
+/* ElementRestriction::Mult, scalar field (fem/restriction.cpp:109-129):
+ * yE[i] = +-x[gather_map[i]], i < nedofs = NE*D1D^3 (negative entries encode -1-idx and a
+ * sign flip). */
+int mfem_amd_restrict_gather(int64_t nedofs, const int *gather_map, const double *x,
+                             double *yE, void *stream);
+/* Same, vector field with vd components (mesh nodes): x ordered byNODES (byvdim = 0) or
+ * byVDIM (1); yE laid out (nd, vd, NE) (fem/restriction.cpp:115-127). */
+int mfem_amd_restrict_gather_vdim(int64_t nedofs, int nd, int vd, int byvdim,
+                                  int64_t ndofs, const int *gather_map, const double *x,
+                                  double *yE, void *stream);
+/* ElementRestriction::TAddMultTranspose<ADD> (add = 0/1) and AbsMultTranspose (absv = 1)
+ * (fem/restriction.cpp:152-180, 196-221): the deterministic transpose-offset gather
+ * y[i] (+)= sum_{j in [offsets[i], offsets[i+1])} +-xE[indices[j]], summed left to right
+ * starting from 0, exactly the reference's order. */
+int mfem_amd_restrict_scatter(int64_t ndofs, const int *offsets, const int *indices,
+                              const double *xE, double *y, int add, int absv,
+                              void *stream);
+
+/* ---- geometric factors and PA setup --------------------------------------------- */
+
+/* GeometricFactors::Compute, JACOBIANS (mesh/mesh.cpp:15178-15231; Derivatives3D,
+ * fem/qinterp/grad.hpp:232-374): nodesE (Dn,Dn,Dn,3,NE) -> J (Q,Q,Q,3,3,NE),
+ * J(q,r,c,e) = dx_r/dxi_c.  Bn, Gn: HOST, nodal basis at the rule's points. */
+int mfem_amd_geom_jacobians_3d(int Dn, int Q1D, int64_t ne, const double *Bn,
+                               const double *Gn, const double *nodesE, double *J,
+                               void *stream);
+/* GeometricFactors DETERMINANTS (fem/qinterp/det.hpp:209-282): detJ (Q,Q,Q,NE) from J. */
+int mfem_amd_geom_det_3d(int Q1D, int64_t ne, const double *J, double *detJ, void *stream);
+/* PADiffusionSetup3D (fem/integ/bilininteg_diffusion_kernels.cpp:243-367), scalar or
+ * vector coefficient (coeffDim 1 or 3): D (Q,Q,Q,6,NE), component order
+ * (1,1),(2,1),(3,1),(2,2),(3,2),(3,3).  C: device; const_c != 0 -> C has coeffDim entries,
+ * else (coeffDim,Q,Q,Q,NE). */
+int mfem_amd_diffusion_setup_3d(int Q1D, int coeffDim, int64_t ne, const double *W,
+                                const double *J, const double *C, int const_c, double *D,
+                                void *stream);
+/* Mass setup (fem/integ/bilininteg_mass_pa.cpp:72-77): D(q,e) = W(q)*c*detJ(q,e). */
+int mfem_amd_mass_setup_3d(int Q1D, int64_t ne, const double *W, const double *detJ,
+                           const double *C, int const_c, double *D, void *stream);
+/* Fused nodes -> D: AssemblePA without materialising J (9*Q^3*NE doubles, 1.5x pa_data;
+ * SURVEY a-6).  kind 0 = mass (D (Q^3,NE)), 1 = diffusion (D (Q^3,6,NE)); coeffDim 1 or 3
+ * (diffusion), 1 (mass).  detJ_out may be NULL; if not, (Q^3,NE) determinants are also
+ * written (needed by the RHS).  Same arithmetic per point as the two-step path. */
+int mfem_amd_pa_setup_from_nodes_3d(int kind, int Dn, int Q1D, int coeffDim, int64_t ne,
+                                    const double *Bn, const double *Gn, const double *W,
+                                    const double *nodesE, const double *C, int const_c,
+                                    double *D, double *detJ_out, void *stream);
+
+/* ---- PA operator action ---------------------------------------------------------- */
+
+/* DiffusionIntegrator::AddMultPA -> ApplyPAKernels::Run -> SmemPADiffusionApply3D<D,Q> /
+ * fallback PADiffusionApply3D (fem/integ/bilininteg_diffusion_pa.cpp:40-74,
+ * fem/integ/bilininteg_diffusion_kernels.hpp:988-1211, 795-985).  Signature mirrors
+ * DiffusionIntegrator::ApplyKernelType (fem/bilininteg.hpp:2181-2185):
+ * yE += G^T D G xE per element.  Only symmetric != 0 (6-component D) is supported. */
+int mfem_amd_pa_diffusion_apply_3d(int D1D, int Q1D, int64_t ne, int symmetric,
+                                   const double *B, const double *G, const double *D,
+                                   const double *xE, double *yE, void *stream);
+/* MassIntegrator::AddMultPA -> SmemPAMassApply3D<D,Q> / PAMassApply3D_Element
+ * (fem/integ/bilininteg_mass_pa.cpp:140-169, bilininteg_mass_kernels.hpp:1119-1144,
+ * 656-805); MassIntegrator::ApplyKernelType (fem/bilininteg.hpp:2387-2393). yE += ... */
+int mfem_amd_pa_mass_apply_3d(int D1D, int Q1D, int64_t ne, const double *B,
+                              const double *D, const double *xE, double *yE, void *stream);
+/* AssembleDiagonalPA: SmemPADiffusionDiagonal3D / SmemPAMassAssembleDiagonal3D
+ * (fem/integ/bilininteg_diffusion_kernels.hpp:368-484, bilininteg_mass_kernels.hpp:324-408;
+ * DiagonalKernelType fem/bilininteg.hpp:2187-2189).  diagE += diag(A_e). */
+int mfem_amd_pa_diffusion_diag_3d(int D1D, int Q1D, int64_t ne, int symmetric,
+                                  const double *B, const double *G, const double *D,
+                                  double *diagE, void *stream);
+int mfem_amd_pa_mass_diag_3d(int D1D, int Q1D, int64_t ne, const double *B,
+                             const double *D, double *diagE, void *stream);
+
+/* PABilinearFormExtension::MultInternal, H1 branch, one integrator
+ * (fem/bilinearform_ext.cpp:487-564): yE = A_E (gather x) with the L->E gather fused into
+ * the element kernel (no localX round trip, no memset of localY).  kind 0 mass / 1
+ * diffusion.  gather_map entries < 0 here mean "use 0.0" (masked essential dofs, see
+ * mfem_amd_mask_gather_map) -- scalar H1 gather maps are never negative in the reference.
+ * Follow with mfem_amd_restrict_scatter[_dot] for the E->L sum. */
+int mfem_amd_pa_apply_L2E(int kind, int D1D, int Q1D, int64_t ne, const double *B,
+                          const double *G, const double *D, const int *gather_map,
+                          const double *x, double *yE, void *stream);
+
+/* ---- ConstrainedOperator (linalg/operator.cpp:511-646) --------------------------- */
+
+/* marker[i] = 1 for i in list (constraint_list -> byte marker), others untouched. */
+int mfem_amd_set_marker(int64_t nlist, const int *list, unsigned char *marker, void *stream);
+/* masked[i] = marker[gather_map[i]] ? -1 : gather_map[i]: folds `z = x; z[ess] = 0`
+ * (linalg/operator.cpp:603-608) into the fused gather. */
+int mfem_amd_mask_gather_map(int64_t nedofs, const int *gather_map,
+                             const unsigned char *marker, int *masked, void *stream);
+/* y[list[i]] = x[list[i]] (linalg/operator.cpp:624-629), or y[list[i]] = value if x NULL
+ * (:608). */
+int mfem_amd_set_subvector(int64_t nlist, const int *list, const double *x, double value,
+                           double *y, void *stream);
+
+/* ---- Vector / reductions (linalg/vector.cpp, general/reducers.hpp) ---------------- */
+
+/* z = a*x + b*y (add(v1,alpha,v2,v) linalg/vector.cpp:436-473, subtract :570; aliasing of
+ * z with x or y allowed).  y may be NULL when b == 0 (copy / scale). */
+int mfem_amd_vec_axpby(int64_t n, double a, const double *x, double b, const double *y,
+                       double *z, void *stream);
+/* x[i] = value (Vector::operator=(double) linalg/vector.cpp:232). */
+int mfem_amd_vec_fill(int64_t n, double value, double *x, void *stream);
+/* Bytes of device workspace the reductions below need (independent of n). */
+int64_t mfem_amd_reduce_workspace_bytes(void);
+/* *result = sum x[i]*y[i] (Vector::operator* linalg/vector.cpp:1079-1152 -> reduce
+ * general/reducers.hpp:531-593).  Deterministic: fixed chunking that depends on n only,
+ * wavefront shuffle + LDS tree, final pass by one workgroup; `result` is a device double.
+ * ws: device workspace of mfem_amd_reduce_workspace_bytes(). */
+int mfem_amd_vec_dot(int64_t n, const double *x, const double *y, double *result,
+                     void *ws, void *stream);
+/* OperatorJacobiSmoother::Setup (linalg/solvers.cpp:401-425):
+ * dinv[i] = damping/diag[i]; dinv[ess[i]] = damping. */
+int mfem_amd_jacobi_setup(int64_t n, const double *diag, double damping, int64_t ness,
+                          const int *ess, double *dinv, void *stream);
+/* OperatorJacobiSmoother::Mult (linalg/solvers.cpp:427-453): z = dinv .* r, one pass. */
+int mfem_amd_jacobi_apply(int64_t n, const double *dinv, const double *r, double *z,
+                          void *stream);
+
+/* ---- Jacobi-PCG on the PA operator, scalars resident on the device ---------------- */
+
+/* Problem description for mfem_amd_pcg_pa (all device pointers unless marked HOST). */
+typedef struct mfem_amd_pa_operator
+{
+   int kind;                 /* 0 mass, 1 diffusion */
+   int D1D, Q1D;
+   int64_t ne, ndofs;
+   const double *B, *G;      /* HOST */
+   const double *pa_data;
+   const int *gather_map;    /* plain gather map (used when ness == 0) */
+   const int *masked_gather_map; /* from mfem_amd_mask_gather_map (used when ness > 0) */
+   const int *offsets, *indices;
+   int64_t ness;
+   const int *ess;           /* constraint_list */
+   const unsigned char *ess_marker; /* ndofs bytes */
+   double *yE;               /* work: NE*D1D^3 doubles */
+} mfem_amd_pa_operator;
+
+/* ConstrainedOperator(PABilinearFormExtension)::Mult, DIAG_ONE
+ * (linalg/operator.cpp:586-646 over fem/bilinearform_ext.cpp:487-564):
+ * y = A z with z = x, z[ess] = 0; y[ess] = x[ess].  Two kernels (fused gather+apply,
+ * transpose-gather with the essential rows patched in). */
+int mfem_amd_pa_constrained_mult(const mfem_amd_pa_operator *op, const double *x, double *y,
+                                 void *stream);
+
+typedef struct mfem_amd_pcg_result
+{
+   int iterations;      /* CGSolver::GetNumIterations */
+   int converged;       /* CGSolver::GetConverged */
+   double initial_nom;  /* (B r, r) at iteration 0 */
+   double final_nom;    /* (B r, r) at the last iteration; final_norm = sqrt */
+} mfem_amd_pcg_result;
+
+/* Bytes of device workspace mfem_amd_pcg_pa needs for n unknowns (3 vectors, reduction
+ * partials, the residual history and the scalar state). */
+int64_t mfem_amd_pcg_workspace_bytes(int64_t n, int max_iter);
+/* CGSolver::Mult with iterative_mode = false (linalg/solvers.cpp:869-1050), preconditioned
+ * by OperatorJacobiSmoother (dinv != NULL) or not (dinv == NULL, bench_ceed.cpp:117-121).
+ * Stopping rule (:919,988): stop when (B r, r) <= max((B r, r)_0*rel_tol^2, abs_tol^2);
+ * max_iter as the reference.  Vector updates are fused (kernel A
+ * {x += alpha d; r -= alpha z; z = dinv r; partial r.z}, kernel B {d = z + beta d}, d.Ad in
+ * the transpose-gather epilogue); alpha, beta, the residual norms and the stop flag live
+ * on the device, so no host synchronisation happens inside the loop: the host polls the
+ * flag every `check_every` iterations (>= 1) and kernels launched after convergence are
+ * no-ops, so the iteration count is exactly the reference's.
+ * hist: HOST, may be NULL, else max_iter+1 doubles = the "(B r, r)" sequence the reference
+ * prints (linalg/solvers.cpp:898-901, 982-986).
+ * This entry point synchronises `stream` (it returns the result to the host). */
+int mfem_amd_pcg_pa(const mfem_amd_pa_operator *op, const double *dinv, const double *b,
+                    double *x, double rel_tol, double abs_tol, int max_iter,
+                    int check_every, void *workspace, mfem_amd_pcg_result *result,
+                    double *hist, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFEM_AMD_H */

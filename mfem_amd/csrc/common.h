@@ -1,0 +1,74 @@
+// Shared helpers for the HIP kernels of libmfem_amd (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdarg>
+#include "../../include/mfem_amd.h"
+
+namespace mfa
+{
+
+constexpr int MAX_D1D = 10;
+constexpr int MAX_Q1D = 14;
+constexpr int MAX_DQ  = 140;   // D1D*Q1D limit of the by-value basis tables
+
+// 1D basis tables passed BY VALUE in the kernel-argument segment: every access with a
+// compile-time (unrolled) index becomes a scalar load into SGPRs, and v_fma_f64 takes the
+// SGPR pair directly -- no LDS or VGPR traffic for B/G in the contraction loops.
+// Layout: b[q*D + d] (q-major, so a thread's row q is contiguous).
+template <int N>
+struct BasisT
+{
+   double b[N];
+   double g[N];
+};
+
+void set_error(const char *fmt, ...);
+int check_hip(hipError_t e, const char *what);
+bool report_kernels_enabled();
+void report_fallback(const char *name, int D1D, int Q1D);
+
+#define MFA_CHECK_LAUNCH(name) \
+   do { if (int rc_ = ::mfa::check_hip(hipGetLastError(), name)) { return rc_; } } while (0)
+
+#define MFA_REQUIRE(cond, ...) \
+   do { if (!(cond)) { ::mfa::set_error(__VA_ARGS__); return 1; } } while (0)
+
+static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// XCD-aware block remap: hardware deals workgroups round-robin over the 8 XCDs, so blocks
+// b and b+8 share an L2.  Map the launch index to a logical block id such that each XCD
+// owns one contiguous range of logical blocks (neighbouring elements share L-dofs, so
+// their x gathers and the straddling cache lines of pa_data hit the same L2).
+// Bijective for any nb (guide: cdna_hip_programming.md, 256^2 template notes).
+__device__ __forceinline__ int64_t xcd_remap(int64_t bid, int64_t nb)
+{
+   const int64_t q = nb >> 3, r = nb & 7;
+   const int64_t xcd = bid & 7, k = bid >> 3;
+   const int64_t base = (xcd < r) ? xcd*(q + 1) : r*(q + 1) + (xcd - r)*q;
+   return base + k;
+}
+
+// Wavefront (64 lanes) sum, result valid in lane 0.
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+   for (int off = 32; off > 0; off >>= 1) { v += __shfl_down(v, off, 64); }
+   return v;
+}
+
+// Workgroup sum for blockDim.x == 256 (4 waves); result valid in thread 0.
+// Fixed tree: lanes by shuffle, then waves 0..3 added in order.
+__device__ __forceinline__ double block_sum_256(double v, double *s4)
+{
+   v = wave_sum(v);
+   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+   if (lane == 0) { s4[w] = v; }
+   __syncthreads();
+   double r = 0.0;
+   if (threadIdx.x == 0) { r = ((s4[0] + s4[1]) + s4[2]) + s4[3]; }
+   return r;
+}
+
+} // namespace mfa

@@ -1,0 +1,521 @@
+// Sum-factorised PA operator action for H1 hexahedra on gfx950 (MI355X).
+//
+// Replaces: SmemPADiffusionApply3D<D,Q> / PADiffusionApply3D
+//           (fem/integ/bilininteg_diffusion_kernels.hpp:988-1211, 795-985),
+//           SmemPAMassApply3D<D,Q> / PAMassApply3D_Element
+//           (fem/integ/bilininteg_mass_kernels.hpp:1119-1144, 807-1033, 656-805),
+//           and, in the fused L->E form, ElementRestriction::Mult
+//           (fem/restriction.cpp:109-129) + the `localY = 0` memset
+//           (fem/bilinearform_ext.cpp:543-548).
+//
+// Design (MI355X-first, not the reference's one-element-per-block Q^3-thread layout):
+//  * A workgroup holds NBZ elements; each element is worked by a Q x Q thread sheet
+//    (thread = (qx,qy)), so Q*Q*NBZ ~ 200..256 threads = 4 full 64-lane wavefronts even at
+//    p = 1 (the reference launches 27 threads per block at p = 1).
+//  * The z direction lives in registers: every thread keeps its z-column of the x/y
+//    contracted fields (3*D doubles), runs the qz loop -- contraction to the quadrature
+//    point, the 3x3 symmetric D matvec, transposed contraction back to D z-values --
+//    entirely in VGPRs.  Only the x and y contractions go through LDS.
+//  * B and G travel in the kernel-argument segment (BasisT by value): the z-direction
+//    factors are wave-uniform and compile-time indexed -> scalar loads + SGPR operands of
+//    v_fma_f64; thread-indexed rows are staged once in LDS.
+//  * pa_data (the dominant HBM stream, 48*Q^3 B per element) is fetched into registers at
+//    the very top of the kernel, before the first barrier, so the whole stream is in
+//    flight while the x/y contractions run; it is read exactly once, in the reference's
+//    (q, component, element) layout.
+//  * Logical block ids are remapped so every XCD (private L2) works on one contiguous
+//    element range.
+#include "common.h"
+
+namespace mfa
+{
+
+constexpr int nbz_for(int Q)
+{
+   return Q <= 2 ? 32 : Q == 3 ? 16 : Q == 4 ? 16 : Q == 5 ? 10 : Q == 6 ? 7 :
+          Q == 7 ? 5 : Q == 8 ? 4 : Q == 9 ? 3 : 2;
+}
+
+// KIND: 0 mass, 1 diffusion.  GATHER: x is an L-vector read through gmap (entries < 0 read
+// as 0.0), else x is an E-vector.  ACCUM: yE += (AddMultPA semantics) else yE =.
+template <int KIND, int D, int Q, int NBZ, bool GATHER, bool ACCUM>
+__global__ void __launch_bounds__(Q*Q*NBZ)
+k_pa_apply(const int64_t ne, const int64_t nblocks, const BasisT<D*Q> bg,
+           const double *__restrict__ Dq, const double *__restrict__ x,
+           const int *__restrict__ gmap, double *__restrict__ yE)
+{
+   constexpr int NC = KIND ? 6 : 1;       // stored components per quadrature point
+   constexpr int NF = KIND ? 3 : 1;       // fields carried through the z loop
+   constexpr int NX = KIND ? 2 : 1;       // fields after the x contraction (B x, G x)
+   constexpr int D3 = D*D*D, DDQ = D*D*Q, DQQ = D*Q*Q, QQ = Q*Q;
+   constexpr int Q3 = Q*Q*Q;
+   constexpr int SA = (D3 + NX*DDQ > NF*DQQ) ? D3 + NX*DDQ : NF*DQQ;
+   constexpr int SV = NX*DDQ;
+   __shared__ double smem[NBZ][SA + SV];
+   __shared__ double sB[Q*D], sG[Q*D];
+
+   const int a = threadIdx.x, b = threadIdx.y, tz = threadIdx.z;
+   const int64_t e = xcd_remap(blockIdx.x, nblocks)*NBZ + tz;
+   const bool active = e < ne;
+
+   // --- the HBM stream: this thread's z-column of pa_data, issued before any barrier
+   double O[Q][NC];
+   if (active)
+   {
+      const double *De = Dq + e*(int64_t)(NC*Q3) + b*Q + a;
+#pragma unroll
+      for (int qz = 0; qz < Q; qz++)
+      {
+#pragma unroll
+         for (int c = 0; c < NC; c++) { O[qz][c] = De[c*Q3 + qz*QQ]; }
+      }
+   }
+   else
+   {
+#pragma unroll
+      for (int qz = 0; qz < Q; qz++)
+      {
+#pragma unroll
+         for (int c = 0; c < NC; c++) { O[qz][c] = 0.0; }
+      }
+   }
+
+   double *sA = smem[tz];
+   double *sX = sA, *sBX = sA + D3, *sGX = sBX + DDQ;   // phase 1 view of region A
+   double *sT = sA;                                     // phase 2 view of region A
+   double *sV = sA + SA;
+
+   const int t2 = a + Q*b;
+   for (int i = t2; i < D3; i += QQ)
+   {
+      double v = 0.0;
+      if (active)
+      {
+         if (GATHER)
+         {
+            const int g = gmap[e*D3 + i];
+            v = (g >= 0) ? x[g] : 0.0;
+         }
+         else { v = x[e*D3 + i]; }
+      }
+      sX[i] = v;
+   }
+   for (int i = t2 + QQ*tz; i < Q*D; i += QQ*NBZ)
+   {
+      sB[i] = bg.b[i];
+      if (KIND) { sG[i] = bg.g[i]; }
+   }
+   __syncthreads();
+
+   // --- x contraction: thread (qx = a, dy = b)
+   if (b < D)
+   {
+      double Ba[D], Ga[D];
+#pragma unroll
+      for (int dx = 0; dx < D; dx++) { Ba[dx] = sB[a*D + dx]; Ga[dx] = KIND ? sG[a*D + dx] : 0.0; }
+#pragma unroll
+      for (int dz = 0; dz < D; dz++)
+      {
+         double u = 0.0, v = 0.0;
+#pragma unroll
+         for (int dx = 0; dx < D; dx++)
+         {
+            const double s = sX[(dz*D + b)*D + dx];
+            u += Ba[dx]*s;
+            if (KIND) { v += Ga[dx]*s; }
+         }
+         sBX[(dz*D + b)*Q + a] = u;
+         if (KIND) { sGX[(dz*D + b)*Q + a] = v; }
+      }
+   }
+   __syncthreads();
+
+   // --- y contraction into register z-columns: thread (qx = a, qy = b)
+   double r1[D], r2[D], r3[D];
+   {
+      double Bb[D], Gb[D];
+#pragma unroll
+      for (int dy = 0; dy < D; dy++) { Bb[dy] = sB[b*D + dy]; Gb[dy] = KIND ? sG[b*D + dy] : 0.0; }
+#pragma unroll
+      for (int dz = 0; dz < D; dz++)
+      {
+         double u = 0.0, v = 0.0, w = 0.0;
+#pragma unroll
+         for (int dy = 0; dy < D; dy++)
+         {
+            const double bx = sBX[(dz*D + dy)*Q + a];
+            w += Bb[dy]*bx;
+            if (KIND)
+            {
+               const double gx = sGX[(dz*D + dy)*Q + a];
+               u += Bb[dy]*gx;
+               v += Gb[dy]*bx;
+            }
+         }
+         r1[dz] = u; r2[dz] = v; r3[dz] = w;
+      }
+   }
+
+   // --- z loop in registers: to the quadrature point, D matvec, back to dofs in z
+   double t1[D], t2r[D], t3[D];
+#pragma unroll
+   for (int dz = 0; dz < D; dz++) { t1[dz] = 0.0; t2r[dz] = 0.0; t3[dz] = 0.0; }
+#pragma unroll
+   for (int qz = 0; qz < Q; qz++)
+   {
+      if (KIND)
+      {
+         double gX = 0.0, gY = 0.0, gZ = 0.0;
+#pragma unroll
+         for (int dz = 0; dz < D; dz++)
+         {
+            const double bz = bg.b[qz*D + dz], gz = bg.g[qz*D + dz];
+            gX += bz*r1[dz];
+            gY += bz*r2[dz];
+            gZ += gz*r3[dz];
+         }
+         const double O11 = O[qz][0], O12 = O[qz][1], O13 = O[qz][2];
+         const double O22 = O[qz][NC > 3 ? 3 : 0], O23 = O[qz][NC > 4 ? 4 : 0], O33 = O[qz][NC > 5 ? 5 : 0];
+         const double fX = (O11*gX) + (O12*gY) + (O13*gZ);
+         const double fY = (O12*gX) + (O22*gY) + (O23*gZ);
+         const double fZ = (O13*gX) + (O23*gY) + (O33*gZ);
+#pragma unroll
+         for (int dz = 0; dz < D; dz++)
+         {
+            const double bz = bg.b[qz*D + dz], gz = bg.g[qz*D + dz];
+            t1[dz] += bz*fX;
+            t2r[dz] += bz*fY;
+            t3[dz] += gz*fZ;
+         }
+      }
+      else
+      {
+         double u = 0.0;
+#pragma unroll
+         for (int dz = 0; dz < D; dz++) { u += bg.b[qz*D + dz]*r3[dz]; }
+         u *= O[qz][0];
+#pragma unroll
+         for (int dz = 0; dz < D; dz++) { t3[dz] += bg.b[qz*D + dz]*u; }
+      }
+   }
+   __syncthreads();   // all reads of sBX/sGX done; region A is reused as sT
+#pragma unroll
+   for (int dz = 0; dz < D; dz++)
+   {
+      sT[dz*QQ + b*Q + a] = t3[dz];
+      if (KIND)
+      {
+         sT[(D + dz)*QQ + b*Q + a] = t2r[dz];
+         sT[(2*D + dz)*QQ + b*Q + a] = t1[dz];
+      }
+   }
+   __syncthreads();
+
+   // --- transposed y contraction: thread (qx = a, dy = b)
+   if (b < D)
+   {
+      double Bc[Q], Gc[Q];
+#pragma unroll
+      for (int qy = 0; qy < Q; qy++) { Bc[qy] = sB[qy*D + b]; Gc[qy] = KIND ? sG[qy*D + b] : 0.0; }
+#pragma unroll
+      for (int dz = 0; dz < D; dz++)
+      {
+         double v1 = 0.0, v23 = 0.0;
+#pragma unroll
+         for (int qy = 0; qy < Q; qy++)
+         {
+            v23 += Bc[qy]*sT[dz*QQ + qy*Q + a];
+            if (KIND)
+            {
+               v23 += Gc[qy]*sT[(D + dz)*QQ + qy*Q + a];
+               v1 += Bc[qy]*sT[(2*D + dz)*QQ + qy*Q + a];
+            }
+         }
+         sV[(dz*D + b)*Q + a] = v23;
+         if (KIND) { sV[DDQ + (dz*D + b)*Q + a] = v1; }
+      }
+   }
+   __syncthreads();
+
+   // --- transposed x contraction and store: thread (dx = a, dy = b)
+   if (a < D && b < D && active)
+   {
+      double Bc[Q], Gc[Q];
+#pragma unroll
+      for (int qx = 0; qx < Q; qx++) { Bc[qx] = sB[qx*D + a]; Gc[qx] = KIND ? sG[qx*D + a] : 0.0; }
+      double *ye = yE + e*D3 + b*D + a;
+#pragma unroll
+      for (int dz = 0; dz < D; dz++)
+      {
+         double y = 0.0;
+#pragma unroll
+         for (int qx = 0; qx < Q; qx++)
+         {
+            y += Bc[qx]*sV[(dz*D + b)*Q + qx];
+            if (KIND) { y += Gc[qx]*sV[DDQ + (dz*D + b)*Q + qx]; }
+         }
+         if (ACCUM) { ye[dz*D*D] += y; }
+         else { ye[dz*D*D] = y; }
+      }
+   }
+}
+
+// ------------------------------------------------------------------------------------
+// Generic fallback (runtime D1D, Q1D), one workgroup per element, everything through LDS.
+// Counterpart of the reference's non-specialised PADiffusionApply3D / PAMassApply3D
+// fallbacks (kernel_dispatch.hpp:176-180).
+// ------------------------------------------------------------------------------------
+template <int KIND, bool GATHER, bool ACCUM>
+__global__ void __launch_bounds__(256)
+k_pa_apply_generic(const int D, const int Q, const int64_t ne, const BasisT<MAX_DQ> bg,
+                   const double *__restrict__ Dq, const double *__restrict__ x,
+                   const int *__restrict__ gmap, double *__restrict__ yE)
+{
+   constexpr int NC = KIND ? 6 : 1, NF = KIND ? 3 : 1, NX = KIND ? 2 : 1;
+   extern __shared__ __align__(16) double dyn[];
+   const int D3 = D*D*D, DDQ = D*D*Q, DQQ = D*Q*Q, Q3 = Q*Q*Q, QQ = Q*Q;
+   double *sB = dyn, *sG = sB + Q*D;
+   double *sX = sG + Q*D;            // D3
+   double *s1 = sX + D3;             // NX*DDQ  [k][dz][dy][qx]
+   double *s2 = s1 + NX*DDQ;         // NF*DQQ  [k][dz][qy][qx]
+   double *s3 = s2 + NF*DQQ;         // NF*Q3   [k][qz][qy][qx]
+   const int tid = threadIdx.x, nt = blockDim.x;
+   const int64_t e = blockIdx.x;
+   for (int i = tid; i < Q*D; i += nt) { sB[i] = bg.b[i]; sG[i] = bg.g[i]; }
+   for (int i = tid; i < D3; i += nt)
+   {
+      double v;
+      if (GATHER) { const int g = gmap[e*D3 + i]; v = (g >= 0) ? x[g] : 0.0; }
+      else { v = x[e*D3 + i]; }
+      sX[i] = v;
+   }
+   __syncthreads();
+   for (int i = tid; i < DDQ; i += nt)
+   {
+      const int qx = i % Q, dy = (i/Q) % D, dz = i/(Q*D);
+      double u = 0.0, v = 0.0;
+      for (int dx = 0; dx < D; dx++)
+      {
+         const double s = sX[(dz*D + dy)*D + dx];
+         u += sB[qx*D + dx]*s;
+         v += sG[qx*D + dx]*s;
+      }
+      s1[i] = u;
+      if (KIND) { s1[DDQ + i] = v; }
+   }
+   __syncthreads();
+   for (int i = tid; i < DQQ; i += nt)
+   {
+      const int qx = i % Q, qy = (i/Q) % Q, dz = i/QQ;
+      double u = 0.0, v = 0.0, w = 0.0;
+      for (int dy = 0; dy < D; dy++)
+      {
+         const double bx = s1[(dz*D + dy)*Q + qx];
+         w += sB[qy*D + dy]*bx;
+         if (KIND)
+         {
+            const double gx = s1[DDQ + (dz*D + dy)*Q + qx];
+            u += sB[qy*D + dy]*gx;
+            v += sG[qy*D + dy]*bx;
+         }
+      }
+      s2[i] = w;
+      if (KIND) { s2[DQQ + i] = v; s2[2*DQQ + i] = u; }
+   }
+   __syncthreads();
+   for (int i = tid; i < Q3; i += nt)
+   {
+      const int qq = i % QQ, qz = i/QQ;
+      const double *De = Dq + e*(int64_t)(NC*Q3) + i;
+      if (KIND)
+      {
+         double gX = 0.0, gY = 0.0, gZ = 0.0;
+         for (int dz = 0; dz < D; dz++)
+         {
+            const double bz = sB[qz*D + dz], gz = sG[qz*D + dz];
+            gX += bz*s2[2*DQQ + dz*QQ + qq];
+            gY += bz*s2[DQQ + dz*QQ + qq];
+            gZ += gz*s2[dz*QQ + qq];
+         }
+         const double O11 = De[0], O12 = De[Q3], O13 = De[2*(int64_t)Q3];
+         const double O22 = De[3*(int64_t)Q3], O23 = De[4*(int64_t)Q3], O33 = De[5*(int64_t)Q3];
+         s3[i] = (O13*gX) + (O23*gY) + (O33*gZ);
+         s3[Q3 + i] = (O12*gX) + (O22*gY) + (O23*gZ);
+         s3[2*Q3 + i] = (O11*gX) + (O12*gY) + (O13*gZ);
+      }
+      else
+      {
+         double u = 0.0;
+         for (int dz = 0; dz < D; dz++) { u += sB[qz*D + dz]*s2[dz*QQ + qq]; }
+         s3[i] = u*De[0];
+      }
+   }
+   __syncthreads();
+   for (int i = tid; i < DQQ; i += nt)   // back in z: [k][dz][qy][qx]
+   {
+      const int qq = i % QQ, dz = i/QQ;
+      double t1 = 0.0, t2 = 0.0, t3 = 0.0;
+      for (int qz = 0; qz < Q; qz++)
+      {
+         const double bz = sB[qz*D + dz], gz = sG[qz*D + dz];
+         if (KIND)
+         {
+            t3 += gz*s3[qz*QQ + qq];
+            t2 += bz*s3[Q3 + qz*QQ + qq];
+            t1 += bz*s3[2*Q3 + qz*QQ + qq];
+         }
+         else { t3 += bz*s3[qz*QQ + qq]; }
+      }
+      s2[i] = t3;
+      if (KIND) { s2[DQQ + i] = t2; s2[2*DQQ + i] = t1; }
+   }
+   __syncthreads();
+   for (int i = tid; i < DDQ; i += nt)   // back in y: [k][dz][dy][qx]
+   {
+      const int qx = i % Q, dy = (i/Q) % D, dz = i/(Q*D);
+      double v1 = 0.0, v23 = 0.0;
+      for (int qy = 0; qy < Q; qy++)
+      {
+         v23 += sB[qy*D + dy]*s2[dz*QQ + qy*Q + qx];
+         if (KIND)
+         {
+            v23 += sG[qy*D + dy]*s2[DQQ + dz*QQ + qy*Q + qx];
+            v1 += sB[qy*D + dy]*s2[2*DQQ + dz*QQ + qy*Q + qx];
+         }
+      }
+      s1[i] = v23;
+      if (KIND) { s1[DDQ + i] = v1; }
+   }
+   __syncthreads();
+   for (int i = tid; i < D3; i += nt)
+   {
+      const int dx = i % D, dyz = i/D;
+      double y = 0.0;
+      for (int qx = 0; qx < Q; qx++)
+      {
+         y += sB[qx*D + dx]*s1[dyz*Q + qx];
+         if (KIND) { y += sG[qx*D + dx]*s1[DDQ + dyz*Q + qx]; }
+      }
+      if (ACCUM) { yE[e*D3 + i] += y; }
+      else { yE[e*D3 + i] = y; }
+   }
+}
+
+// ------------------------------------------------------------------------------------
+// Dispatch: (D1D,Q1D) -> specialised launcher, like MFEM's KernelDispatchTable
+// (fem/kernel_dispatch.hpp:131-181).  Registered: D1D = 2..9 with Q1D in {D1D, D1D+1}
+// (BP5 collocated GLL and BP1/BP3/ex1 Gauss-Legendre p+2), i.e. p = 1..8.
+// ------------------------------------------------------------------------------------
+template <int N>
+static void fill_basis(BasisT<N> &bg, int D, int Q, const double *B, const double *G)
+{
+   for (int q = 0; q < Q; q++)
+   {
+      for (int d = 0; d < D; d++)
+      {
+         bg.b[q*D + d] = B[q + Q*d];
+         bg.g[q*D + d] = G ? G[q + Q*d] : 0.0;
+      }
+   }
+}
+
+typedef int (*apply_fn)(int64_t ne, const double *B, const double *G, const double *Dq,
+                        const double *x, const int *gmap, double *yE, hipStream_t s);
+
+template <int KIND, int D, int Q, bool GATHER, bool ACCUM>
+static int launch_apply(int64_t ne, const double *B, const double *G, const double *Dq,
+                        const double *x, const int *gmap, double *yE, hipStream_t s)
+{
+   constexpr int NBZ = nbz_for(Q);
+   BasisT<D*Q> bg;
+   fill_basis(bg, D, Q, B, G);
+   const int64_t nb = (ne + NBZ - 1)/NBZ;
+   if (nb == 0) { return 0; }
+   MFA_REQUIRE(nb < (int64_t)2147483647, "pa_apply: too many workgroups (%lld)", (long long)nb);
+   k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM><<<dim3((unsigned)nb), dim3(Q, Q, NBZ), 0, s>>>(
+      ne, nb, bg, Dq, x, gmap, yE);
+   MFA_CHECK_LAUNCH("k_pa_apply");
+   return 0;
+}
+
+template <int KIND, bool GATHER, bool ACCUM>
+static apply_fn find_apply(int D, int Q)
+{
+#define MFA_CASE(DD, QQ) \
+   if (D == DD && Q == QQ) { return launch_apply<KIND, DD, QQ, GATHER, ACCUM>; }
+   MFA_CASE(2, 2) MFA_CASE(2, 3) MFA_CASE(3, 3) MFA_CASE(3, 4) MFA_CASE(4, 4) MFA_CASE(4, 5)
+   MFA_CASE(5, 5) MFA_CASE(5, 6) MFA_CASE(6, 6) MFA_CASE(6, 7) MFA_CASE(7, 7) MFA_CASE(7, 8)
+   MFA_CASE(8, 8) MFA_CASE(8, 9) MFA_CASE(9, 9) MFA_CASE(9, 10)
+#undef MFA_CASE
+   return nullptr;
+}
+
+template <int KIND, bool GATHER, bool ACCUM>
+static int run_apply(int D, int Q, int64_t ne, const double *B, const double *G,
+                     const double *Dq, const double *x, const int *gmap, double *yE,
+                     hipStream_t s)
+{
+   MFA_REQUIRE(D >= 2 && D <= MAX_D1D && Q >= 1 && Q <= MAX_Q1D && D*Q <= MAX_DQ,
+               "pa_apply: unsupported (D1D,Q1D) = (%d,%d); limits D1D<=%d, Q1D<=%d, D1D*Q1D<=%d",
+               D, Q, MAX_D1D, MAX_Q1D, MAX_DQ);
+   MFA_REQUIRE(B && Dq && x && yE && (KIND == 0 || G) && (!GATHER || gmap), "pa_apply: null pointer argument");
+   if (apply_fn f = find_apply<KIND, GATHER, ACCUM>(D, Q)) { return f(ne, B, G, Dq, x, gmap, yE, s); }
+   report_fallback(KIND ? "PADiffusionApply3D" : "PAMassApply3D", D, Q);
+   if (ne == 0) { return 0; }
+   MFA_REQUIRE(ne < (int64_t)2147483647, "pa_apply: too many elements for the fallback kernel");
+   BasisT<MAX_DQ> bg;
+   fill_basis(bg, D, Q, B, G);
+   constexpr int NF = KIND ? 3 : 1, NX = KIND ? 2 : 1;
+   const size_t lds = sizeof(double)*(size_t)(2*Q*D + D*D*D + NX*D*D*Q + NF*D*Q*Q + NF*Q*Q*Q);
+   MFA_REQUIRE(lds <= 160*1024, "pa_apply: fallback kernel needs %zu B of LDS (> 160 KiB)", lds);
+   auto kern = k_pa_apply_generic<KIND, GATHER, ACCUM>;
+   if (lds > 64*1024)
+   {
+      if (int rc = check_hip(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                             "hipFuncSetAttribute")) { return rc; }
+   }
+   kern<<<dim3((unsigned)ne), dim3(256), lds, s>>>(D, Q, ne, bg, Dq, x, gmap, yE);
+   MFA_CHECK_LAUNCH("k_pa_apply_generic");
+   return 0;
+}
+
+int pa_apply_L2E(int kind, int D, int Q, int64_t ne, const double *B, const double *G,
+                 const double *Dq, const int *gmap, const double *x, double *yE, hipStream_t s)
+{
+   if (kind == 0) { return run_apply<0, true, false>(D, Q, ne, B, G, Dq, x, gmap, yE, s); }
+   return run_apply<1, true, false>(D, Q, ne, B, G, Dq, x, gmap, yE, s);
+}
+
+} // namespace mfa
+
+using namespace mfa;
+
+extern "C" int mfem_amd_has_specialization(int kind, int D1D, int Q1D)
+{
+   if (kind == 0) { return find_apply<0, false, true>(D1D, Q1D) != nullptr; }
+   return find_apply<1, false, true>(D1D, Q1D) != nullptr;
+}
+
+extern "C" int mfem_amd_pa_diffusion_apply_3d(int D1D, int Q1D, int64_t ne, int symmetric,
+                                              const double *B, const double *G,
+                                              const double *D, const double *xE, double *yE,
+                                              void *stream)
+{
+   MFA_REQUIRE(symmetric, "pa_diffusion_apply_3d: only the symmetric (6-component) D is supported");
+   return run_apply<1, false, true>(D1D, Q1D, ne, B, G, D, xE, nullptr, yE, as_stream(stream));
+}
+
+extern "C" int mfem_amd_pa_mass_apply_3d(int D1D, int Q1D, int64_t ne, const double *B,
+                                         const double *D, const double *xE, double *yE,
+                                         void *stream)
+{
+   return run_apply<0, false, true>(D1D, Q1D, ne, B, nullptr, D, xE, nullptr, yE, as_stream(stream));
+}
+
+extern "C" int mfem_amd_pa_apply_L2E(int kind, int D1D, int Q1D, int64_t ne, const double *B,
+                                     const double *G, const double *D, const int *gather_map,
+                                     const double *x, double *yE, void *stream)
+{
+   MFA_REQUIRE(kind == 0 || kind == 1, "pa_apply_L2E: kind must be 0 (mass) or 1 (diffusion)");
+   return pa_apply_L2E(kind, D1D, Q1D, ne, B, G, D, gather_map, x, yE, as_stream(stream));
+}

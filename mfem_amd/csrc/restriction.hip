@@ -1,0 +1,212 @@
+// ElementRestriction L<->E maps and the ConstrainedOperator index kernels (gfx950).
+//
+// Replaces fem/restriction.cpp:109-129 (Mult), :152-180 (TAddMultTranspose<ADD>),
+// :196-221 (AbsMultTranspose) and the index lambdas of linalg/operator.cpp:567-629.
+// These are pure HBM-bound index streams: one thread per entry, coalesced int32 index
+// reads, indexed fp64 reads served by L2 / Infinity Cache.  The E->L direction is the
+// reference's deterministic transpose-offset gather (sequential left-to-right sum from 0
+// over indices[offsets[i]..offsets[i+1])), so results are bit-reproducible -- no atomics.
+#include "common.h"
+
+namespace mfa
+{
+
+__global__ void __launch_bounds__(256)
+k_gather(const int64_t n, const int *__restrict__ gmap, const double *__restrict__ x,
+         double *__restrict__ yE)
+{
+   const int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x;
+   if (i >= n) { return; }
+   const int g = gmap[i];
+   const double v = x[g >= 0 ? g : -1 - g];
+   yE[i] = g >= 0 ? v : -v;
+}
+
+__global__ void __launch_bounds__(256)
+k_gather_vdim(const int64_t n, const int nd, const int vd, const int byvdim,
+              const int64_t ndofs, const int *__restrict__ gmap,
+              const double *__restrict__ x, double *__restrict__ yE)
+{
+   const int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x;
+   if (i >= n) { return; }
+   const int g = gmap[i];
+   const int64_t j = g >= 0 ? g : -1 - g;
+   const int64_t e = i/nd, l = i % nd;
+   for (int c = 0; c < vd; c++)
+   {
+      const double v = byvdim ? x[c + (int64_t)vd*j] : x[j + c*ndofs];
+      yE[l + nd*(c + (int64_t)vd*e)] = g >= 0 ? v : -v;
+   }
+}
+
+// MODE 0: y = sum, 1: y += sum, 2: y = sum of absolute-index entries (no signs).
+// DOT: additionally accumulate sum_i w[i]*y[i] into per-block partials (CG: d.Ad folded
+// into the transpose-gather epilogue).  marker/xin: rows with marker[i] != 0 take xin[i]
+// (ConstrainedOperator y[ess] = x[ess], linalg/operator.cpp:624-629).  skip: optional
+// device flag; non-zero -> whole kernel is a no-op (converged PCG).
+template <int MODE, bool DOT>
+__global__ void __launch_bounds__(256)
+k_scatter(const int64_t ndofs, const int *__restrict__ offsets,
+          const int *__restrict__ indices, const double *__restrict__ xE,
+          double *__restrict__ y, const unsigned char *__restrict__ marker,
+          const double *__restrict__ xin, const double *__restrict__ w,
+          double *__restrict__ partials, const int *__restrict__ skip)
+{
+   __shared__ double s4[4];
+   if (skip && *skip) { return; }
+   double prod = 0.0;
+   for (int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x; i < ndofs; i += (int64_t)gridDim.x*256)
+   {
+      const int o0 = offsets[i], o1 = offsets[i + 1];
+      double v = 0.0;
+      for (int j = o0; j < o1; j++)
+      {
+         const int idx = indices[j];
+         const double t = xE[idx >= 0 ? idx : -1 - idx];
+         v += (idx >= 0 || MODE == 2) ? t : -t;
+      }
+      if (marker && marker[i]) { v = xin[i]; }
+      if (MODE == 1) { v += y[i]; }
+      y[i] = v;
+      if (DOT) { prod += w[i]*v; }
+   }
+   if (DOT)
+   {
+      const double r = block_sum_256(prod, s4);
+      if (threadIdx.x == 0) { partials[blockIdx.x] = r; }
+   }
+}
+
+__global__ void __launch_bounds__(256)
+k_set_marker(const int64_t n, const int *__restrict__ list, unsigned char *__restrict__ marker)
+{
+   const int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x;
+   if (i < n) { marker[list[i]] = 1; }
+}
+
+__global__ void __launch_bounds__(256)
+k_mask_gather(const int64_t n, const int *__restrict__ gmap,
+              const unsigned char *__restrict__ marker, int *__restrict__ out)
+{
+   const int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x;
+   if (i >= n) { return; }
+   const int g = gmap[i];
+   out[i] = marker[g] ? -1 : g;
+}
+
+__global__ void __launch_bounds__(256)
+k_set_subvector(const int64_t n, const int *__restrict__ list, const double *__restrict__ x,
+                const double value, double *__restrict__ y)
+{
+   const int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x;
+   if (i >= n) { return; }
+   const int k = list[i];
+   y[k] = x ? x[k] : value;
+}
+
+static inline unsigned grid_for(int64_t n) { return (unsigned)((n + 255)/256); }
+
+// E->L with the fused dot; nblocks partials are written (fixed by the caller from n only).
+int scatter_dot(int64_t ndofs, const int *offsets, const int *indices, const double *xE,
+                double *y, const unsigned char *marker, const double *xin, const double *w,
+                double *partials, int nblocks, const int *skip, hipStream_t s)
+{
+   if (w)
+   {
+      k_scatter<0, true><<<dim3(nblocks), dim3(256), 0, s>>>(ndofs, offsets, indices, xE, y,
+                                                           marker, xin, w, partials, skip);
+   }
+   else
+   {
+      k_scatter<0, false><<<dim3(nblocks), dim3(256), 0, s>>>(ndofs, offsets, indices, xE, y,
+                                                            marker, xin, nullptr, nullptr, skip);
+   }
+   MFA_CHECK_LAUNCH("k_scatter");
+   return 0;
+}
+
+} // namespace mfa
+
+using namespace mfa;
+
+extern "C" int mfem_amd_restrict_gather(int64_t nedofs, const int *gather_map,
+                                        const double *x, double *yE, void *stream)
+{
+   if (nedofs == 0) { return 0; }
+   MFA_REQUIRE(nedofs > 0 && gather_map && x && yE, "restrict_gather: bad arguments");
+   MFA_REQUIRE(nedofs < ((int64_t)1 << 39), "restrict_gather: nedofs too large");
+   k_gather<<<dim3(grid_for(nedofs)), dim3(256), 0, as_stream(stream)>>>(nedofs, gather_map, x, yE);
+   MFA_CHECK_LAUNCH("k_gather");
+   return 0;
+}
+
+extern "C" int mfem_amd_restrict_gather_vdim(int64_t nedofs, int nd, int vd, int byvdim,
+                                             int64_t ndofs, const int *gather_map,
+                                             const double *x, double *yE, void *stream)
+{
+   if (nedofs == 0) { return 0; }
+   MFA_REQUIRE(nedofs > 0 && nd > 0 && vd > 0 && nedofs % nd == 0 && gather_map && x && yE,
+               "restrict_gather_vdim: bad arguments");
+   k_gather_vdim<<<dim3(grid_for(nedofs)), dim3(256), 0, as_stream(stream)>>>(
+      nedofs, nd, vd, byvdim, ndofs, gather_map, x, yE);
+   MFA_CHECK_LAUNCH("k_gather_vdim");
+   return 0;
+}
+
+extern "C" int mfem_amd_restrict_scatter(int64_t ndofs, const int *offsets, const int *indices,
+                                         const double *xE, double *y, int add, int absv,
+                                         void *stream)
+{
+   if (ndofs == 0) { return 0; }
+   MFA_REQUIRE(ndofs > 0 && offsets && indices && xE && y, "restrict_scatter: bad arguments");
+   MFA_REQUIRE(!(add && absv), "restrict_scatter: add and abs cannot be combined");
+   const unsigned nb = grid_for(ndofs);
+   hipStream_t s = as_stream(stream);
+   if (absv)
+   {
+      k_scatter<2, false><<<dim3(nb), dim3(256), 0, s>>>(ndofs, offsets, indices, xE, y, nullptr,
+                                                       nullptr, nullptr, nullptr, nullptr);
+   }
+   else if (add)
+   {
+      k_scatter<1, false><<<dim3(nb), dim3(256), 0, s>>>(ndofs, offsets, indices, xE, y, nullptr,
+                                                       nullptr, nullptr, nullptr, nullptr);
+   }
+   else
+   {
+      k_scatter<0, false><<<dim3(nb), dim3(256), 0, s>>>(ndofs, offsets, indices, xE, y, nullptr,
+                                                       nullptr, nullptr, nullptr, nullptr);
+   }
+   MFA_CHECK_LAUNCH("k_scatter");
+   return 0;
+}
+
+extern "C" int mfem_amd_set_marker(int64_t nlist, const int *list, unsigned char *marker,
+                                   void *stream)
+{
+   if (nlist == 0) { return 0; }
+   MFA_REQUIRE(nlist > 0 && list && marker, "set_marker: bad arguments");
+   k_set_marker<<<dim3(grid_for(nlist)), dim3(256), 0, as_stream(stream)>>>(nlist, list, marker);
+   MFA_CHECK_LAUNCH("k_set_marker");
+   return 0;
+}
+
+extern "C" int mfem_amd_mask_gather_map(int64_t nedofs, const int *gather_map,
+                                        const unsigned char *marker, int *masked, void *stream)
+{
+   if (nedofs == 0) { return 0; }
+   MFA_REQUIRE(nedofs > 0 && gather_map && marker && masked, "mask_gather_map: bad arguments");
+   k_mask_gather<<<dim3(grid_for(nedofs)), dim3(256), 0, as_stream(stream)>>>(nedofs, gather_map, marker, masked);
+   MFA_CHECK_LAUNCH("k_mask_gather");
+   return 0;
+}
+
+extern "C" int mfem_amd_set_subvector(int64_t nlist, const int *list, const double *x,
+                                      double value, double *y, void *stream)
+{
+   if (nlist == 0) { return 0; }
+   MFA_REQUIRE(nlist > 0 && list && y, "set_subvector: bad arguments");
+   k_set_subvector<<<dim3(grid_for(nlist)), dim3(256), 0, as_stream(stream)>>>(nlist, list, x, value, y);
+   MFA_CHECK_LAUNCH("k_set_subvector");
+   return 0;
+}

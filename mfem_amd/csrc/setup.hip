@@ -1,0 +1,412 @@
+// PA setup on gfx950: geometric factors, quadrature-point data, element diagonals.
+//
+// Replaces GeometricFactors::Compute + Derivatives3D/Det3D (mesh/mesh.cpp:15178-15231,
+// fem/qinterp/grad.hpp:232-374, fem/qinterp/det.hpp:209-282), PADiffusionSetup3D
+// (fem/integ/bilininteg_diffusion_kernels.cpp:243-367), the mass setup lambda
+// (fem/integ/bilininteg_mass_pa.cpp:72-77), SmemPADiffusionDiagonal3D
+// (fem/integ/bilininteg_diffusion_kernels.hpp:368-484) and SmemPAMassAssembleDiagonal3D
+// (fem/integ/bilininteg_mass_kernels.hpp:324-408).
+//
+// All of these run once per operator (setup), are HBM-bound streams, and take runtime
+// (Dn, Q1D) so that any nodal order of a curved mesh works.  The fused nodes->D kernel
+// never materialises J (9*Q^3*NE doubles = 1.5x the size of pa_data): it reads 3*Dn^3
+// doubles of nodes per element and writes the 6*Q^3 (or Q^3) doubles of D once.
+#include "common.h"
+
+namespace mfa
+{
+
+// J at the quadrature points of one element from its E-nodes, by sum factorisation
+// through LDS.  On return (after the trailing barrier) thread-strided q-points can read
+//   J(r,c) at point q  =  sJ[(r*3 + c)*Q3 + q].
+// LDS layout (doubles): sB[Q*Dn] sG[Q*Dn] sN[3*Dn^3] s1[3*2*Dn^2*Q] s2[3*3*Dn*Q^2] sJ[9*Q^3]
+__device__ __forceinline__ void element_jacobians(const int Dn, const int Q,
+                                                  const BasisT<MAX_DQ> &bg,
+                                                  const double *__restrict__ nodesE_e,
+                                                  double *dyn, double *&sJ_out)
+{
+   const int D3 = Dn*Dn*Dn, DDQ = Dn*Dn*Q, DQQ = Dn*Q*Q, Q3 = Q*Q*Q, QQ = Q*Q;
+   double *sB = dyn, *sG = sB + Q*Dn, *sN = sG + Q*Dn;
+   double *s1 = sN + 3*D3, *s2 = s1 + 6*DDQ, *sJ = s2 + 9*DQQ;
+   const int tid = threadIdx.x, nt = blockDim.x;
+   for (int i = tid; i < Q*Dn; i += nt) { sB[i] = bg.b[i]; sG[i] = bg.g[i]; }
+   for (int i = tid; i < 3*D3; i += nt) { sN[i] = nodesE_e[i]; }
+   __syncthreads();
+   for (int i = tid; i < 3*DDQ; i += nt)        // [r][dz][dy][qx] : B and G along x
+   {
+      const int r = i/DDQ, j = i % DDQ;
+      const int qx = j % Q, dyz = j/Q;
+      double u = 0.0, v = 0.0;
+      for (int dx = 0; dx < Dn; dx++)
+      {
+         const double s = sN[r*D3 + dyz*Dn + dx];
+         u += sB[qx*Dn + dx]*s;
+         v += sG[qx*Dn + dx]*s;
+      }
+      s1[(2*r)*DDQ + j] = u;
+      s1[(2*r + 1)*DDQ + j] = v;
+   }
+   __syncthreads();
+   for (int i = tid; i < 3*DQQ; i += nt)        // [r][c][dz][qy][qx]
+   {
+      const int r = i/DQQ, j = i % DQQ;
+      const int qx = j % Q, qy = (j/Q) % Q, dz = j/QQ;
+      double u = 0.0, v = 0.0, w = 0.0;
+      for (int dy = 0; dy < Dn; dy++)
+      {
+         const double bx = s1[(2*r)*DDQ + (dz*Dn + dy)*Q + qx];
+         const double gx = s1[(2*r + 1)*DDQ + (dz*Dn + dy)*Q + qx];
+         u += gx*sB[qy*Dn + dy];
+         v += bx*sG[qy*Dn + dy];
+         w += bx*sB[qy*Dn + dy];
+      }
+      s2[(3*r + 0)*DQQ + j] = u;
+      s2[(3*r + 1)*DQQ + j] = v;
+      s2[(3*r + 2)*DQQ + j] = w;
+   }
+   __syncthreads();
+   for (int i = tid; i < 3*Q3; i += nt)         // J(r, c) at q
+   {
+      const int r = i/Q3, q = i % Q3;
+      const int qq = q % QQ, qz = q/QQ;
+      double u = 0.0, v = 0.0, w = 0.0;
+      for (int dz = 0; dz < Dn; dz++)
+      {
+         const double bz = sB[qz*Dn + dz], gz = sG[qz*Dn + dz];
+         u += s2[(3*r + 0)*DQQ + dz*QQ + qq]*bz;
+         v += s2[(3*r + 1)*DQQ + dz*QQ + qq]*bz;
+         w += s2[(3*r + 2)*DQQ + dz*QQ + qq]*gz;
+      }
+      sJ[(r*3 + 0)*Q3 + q] = u;
+      sJ[(r*3 + 1)*Q3 + q] = v;
+      sJ[(r*3 + 2)*Q3 + q] = w;
+   }
+   __syncthreads();
+   sJ_out = sJ;
+}
+
+static size_t jac_lds_bytes(int Dn, int Q)
+{
+   return sizeof(double)*(size_t)(2*Q*Dn + 3*Dn*Dn*Dn + 6*Dn*Dn*Q + 9*Dn*Q*Q + 9*Q*Q*Q);
+}
+
+__global__ void __launch_bounds__(256)
+k_jacobians(const int Dn, const int Q, const BasisT<MAX_DQ> bg,
+            const double *__restrict__ nodesE, double *__restrict__ J)
+{
+   extern __shared__ __align__(16) double dyn[];
+   const int64_t e = blockIdx.x;
+   const int Q3 = Q*Q*Q;
+   double *sJ;
+   element_jacobians(Dn, Q, bg, nodesE + e*(int64_t)(3*Dn*Dn*Dn), dyn, sJ);
+   // reference layout J(q, r, c, e): q + Q3*(r + 3*(c + 3*e))
+   for (int i = threadIdx.x; i < 9*Q3; i += blockDim.x)
+   {
+      const int rc = i/Q3, q = i % Q3, r = rc/3, c = rc % 3;
+      J[q + (int64_t)Q3*(r + 3*(c + 3*e))] = sJ[i];
+   }
+}
+
+__device__ __forceinline__ void diffusion_point(const double J11, const double J21, const double J31,
+                                                const double J12, const double J22, const double J32,
+                                                const double J13, const double J23, const double J33,
+                                                const double W, const double C1, const double C2,
+                                                const double C3, double *out, double &detJ)
+{
+   detJ = J11*(J22*J33 - J32*J23) - J21*(J12*J33 - J32*J13) + J31*(J12*J23 - J22*J13);
+   const double w_detJ = W/detJ;
+   const double A11 = (J22*J33) - (J23*J32);
+   const double A12 = (J32*J13) - (J12*J33);
+   const double A13 = (J12*J23) - (J22*J13);
+   const double A21 = (J31*J23) - (J21*J33);
+   const double A22 = (J11*J33) - (J13*J31);
+   const double A23 = (J21*J13) - (J11*J23);
+   const double A31 = (J21*J32) - (J31*J22);
+   const double A32 = (J31*J12) - (J11*J32);
+   const double A33 = (J11*J22) - (J12*J21);
+   out[0] = w_detJ*(C1*A11*A11 + C2*A12*A12 + C3*A13*A13);
+   out[1] = w_detJ*(C1*A11*A21 + C2*A12*A22 + C3*A13*A23);
+   out[2] = w_detJ*(C1*A11*A31 + C2*A12*A32 + C3*A13*A33);
+   out[3] = w_detJ*(C1*A21*A21 + C2*A22*A22 + C3*A23*A23);
+   out[4] = w_detJ*(C1*A21*A31 + C2*A22*A32 + C3*A23*A33);
+   out[5] = w_detJ*(C1*A31*A31 + C2*A32*A32 + C3*A33*A33);
+}
+
+// kind 0: mass, 1: diffusion.  One workgroup per element.
+__global__ void __launch_bounds__(256)
+k_setup_from_nodes(const int kind, const int Dn, const int Q, const int coeffDim,
+                   const BasisT<MAX_DQ> bg, const double *__restrict__ W,
+                   const double *__restrict__ nodesE, const double *__restrict__ C,
+                   const int const_c, double *__restrict__ D, double *__restrict__ detJ_out)
+{
+   extern __shared__ __align__(16) double dyn[];
+   const int64_t e = blockIdx.x;
+   const int Q3 = Q*Q*Q;
+   double *sJ;
+   element_jacobians(Dn, Q, bg, nodesE + e*(int64_t)(3*Dn*Dn*Dn), dyn, sJ);
+   for (int q = threadIdx.x; q < Q3; q += blockDim.x)
+   {
+      const double J11 = sJ[0*Q3 + q], J12 = sJ[1*Q3 + q], J13 = sJ[2*Q3 + q];
+      const double J21 = sJ[3*Q3 + q], J22 = sJ[4*Q3 + q], J23 = sJ[5*Q3 + q];
+      const double J31 = sJ[6*Q3 + q], J32 = sJ[7*Q3 + q], J33 = sJ[8*Q3 + q];
+      const double *c = const_c ? C : C + coeffDim*(q + (int64_t)Q3*e);
+      double out[6], detJ;
+      if (kind)
+      {
+         const double C1 = c[0], C2 = c[coeffDim == 3 ? 1 : 0], C3 = c[coeffDim == 3 ? 2 : 0];
+         diffusion_point(J11, J21, J31, J12, J22, J32, J13, J23, J33, W[q], C1, C2, C3, out, detJ);
+         for (int k = 0; k < 6; k++) { D[q + (int64_t)Q3*(k + 6*e)] = out[k]; }
+      }
+      else
+      {
+         detJ = J11*(J22*J33 - J32*J23) - J21*(J12*J33 - J32*J13) + J31*(J12*J23 - J22*J13);
+         D[q + (int64_t)Q3*e] = W[q]*c[0]*detJ;
+      }
+      if (detJ_out) { detJ_out[q + (int64_t)Q3*e] = detJ; }
+   }
+}
+
+__global__ void __launch_bounds__(256)
+k_det(const int64_t n, const int Q3, const double *__restrict__ J, double *__restrict__ detJ)
+{
+   const int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x;
+   if (i >= n) { return; }
+   const int64_t e = i/Q3, q = i % Q3;
+   const double *Je = J + 9*(int64_t)Q3*e + q;
+   const double J11 = Je[0], J21 = Je[Q3], J31 = Je[2*(int64_t)Q3];
+   const double J12 = Je[3*(int64_t)Q3], J22 = Je[4*(int64_t)Q3], J32 = Je[5*(int64_t)Q3];
+   const double J13 = Je[6*(int64_t)Q3], J23 = Je[7*(int64_t)Q3], J33 = Je[8*(int64_t)Q3];
+   detJ[i] = J11*(J22*J33 - J32*J23) - J21*(J12*J33 - J32*J13) + J31*(J12*J23 - J22*J13);
+}
+
+__global__ void __launch_bounds__(256)
+k_diffusion_setup(const int64_t n, const int Q3, const int coeffDim,
+                  const double *__restrict__ W, const double *__restrict__ J,
+                  const double *__restrict__ C, const int const_c, double *__restrict__ D)
+{
+   const int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x;
+   if (i >= n) { return; }
+   const int64_t e = i/Q3, q = i % Q3;
+   const double *Je = J + 9*(int64_t)Q3*e + q;
+   const double J11 = Je[0], J21 = Je[Q3], J31 = Je[2*(int64_t)Q3];
+   const double J12 = Je[3*(int64_t)Q3], J22 = Je[4*(int64_t)Q3], J32 = Je[5*(int64_t)Q3];
+   const double J13 = Je[6*(int64_t)Q3], J23 = Je[7*(int64_t)Q3], J33 = Je[8*(int64_t)Q3];
+   const double *c = const_c ? C : C + coeffDim*i;
+   const double C1 = c[0], C2 = c[coeffDim == 3 ? 1 : 0], C3 = c[coeffDim == 3 ? 2 : 0];
+   double out[6], detJ;
+   diffusion_point(J11, J21, J31, J12, J22, J32, J13, J23, J33, W[q], C1, C2, C3, out, detJ);
+   for (int k = 0; k < 6; k++) { D[q + (int64_t)Q3*(k + 6*e)] = out[k]; }
+}
+
+__global__ void __launch_bounds__(256)
+k_mass_setup(const int64_t n, const int Q3, const double *__restrict__ W,
+             const double *__restrict__ detJ, const double *__restrict__ C, const int const_c,
+             double *__restrict__ D)
+{
+   const int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x;
+   if (i >= n) { return; }
+   const double coeff = const_c ? C[0] : C[i];
+   D[i] = W[i % Q3]*coeff*detJ[i];
+}
+
+// Element diagonals, one workgroup per element (runtime D, Q).  Same contraction order as
+// the reference kernels (z, then y, then x; 9 (i,j) passes for diffusion).
+template <int KIND>
+__global__ void __launch_bounds__(256)
+k_diag(const int D, const int Q, const BasisT<MAX_DQ> bg, const double *__restrict__ Dq,
+       double *__restrict__ Y)
+{
+   extern __shared__ __align__(16) double dyn[];
+   const int Q3 = Q*Q*Q, QQ = Q*Q, D3 = D*D*D;
+   double *sB = dyn, *sG = sB + Q*D, *QQD = sG + Q*D, *QDD = QQD + Q*Q*D;
+   const int tid = threadIdx.x, nt = blockDim.x;
+   const int64_t e = blockIdx.x;
+   for (int i = tid; i < Q*D; i += nt) { sB[i] = bg.b[i]; sG[i] = bg.g[i]; }
+   __syncthreads();
+   const int npass = KIND ? 9 : 1;
+   for (int pass = 0; pass < npass; pass++)
+   {
+      const int ii = pass/3, jj = pass % 3;
+      const int k = KIND ? (jj >= ii ? 3 - (3 - ii)*(2 - ii)/2 + jj : 3 - (3 - jj)*(2 - jj)/2 + ii) : 0;
+      const double *De = Dq + (int64_t)Q3*(k + (KIND ? 6 : 1)*e);
+      for (int i = tid; i < QQ*D; i += nt)        // [qx][qy][dz]
+      {
+         const int dz = i % D, qy = (i/D) % Q, qx = i/(D*Q);
+         double s = 0.0;
+         for (int qz = 0; qz < Q; qz++)
+         {
+            const double O = De[qx + Q*(qy + Q*qz)];
+            const double Bz = sB[qz*D + dz], Gz = sG[qz*D + dz];
+            const double L = (KIND && ii == 2) ? Gz : Bz, R = (KIND && jj == 2) ? Gz : Bz;
+            s += L*O*R;
+         }
+         QQD[i] = s;
+      }
+      __syncthreads();
+      for (int i = tid; i < Q*D*D; i += nt)       // [qx][dy][dz]
+      {
+         const int dz = i % D, dy = (i/D) % D, qx = i/(D*D);
+         double s = 0.0;
+         for (int qy = 0; qy < Q; qy++)
+         {
+            const double By = sB[qy*D + dy], Gy = sG[qy*D + dy];
+            const double L = (KIND && ii == 1) ? Gy : By, R = (KIND && jj == 1) ? Gy : By;
+            s += L*QQD[(qx*Q + qy)*D + dz]*R;
+         }
+         QDD[i] = s;
+      }
+      __syncthreads();
+      for (int i = tid; i < D3; i += nt)
+      {
+         const int dx = i % D, dy = (i/D) % D, dz = i/(D*D);
+         double s = 0.0;
+         for (int qx = 0; qx < Q; qx++)
+         {
+            const double Bx = sB[qx*D + dx], Gx = sG[qx*D + dx];
+            const double L = (KIND && ii == 0) ? Gx : Bx, R = (KIND && jj == 0) ? Gx : Bx;
+            s += L*QDD[(qx*D + dy)*D + dz]*R;
+         }
+         Y[e*D3 + i] += s;
+      }
+      __syncthreads();
+   }
+}
+
+static int fill_basis_dyn(BasisT<MAX_DQ> &bg, int D, int Q, const double *B, const double *G)
+{
+   MFA_REQUIRE(D >= 1 && D <= MAX_D1D && Q >= 1 && Q <= MAX_Q1D && D*Q <= MAX_DQ,
+               "unsupported (D1D,Q1D) = (%d,%d); limits D1D<=%d, Q1D<=%d, D1D*Q1D<=%d", D, Q,
+               MAX_D1D, MAX_Q1D, MAX_DQ);
+   MFA_REQUIRE(B, "null basis table");
+   for (int q = 0; q < Q; q++)
+      for (int d = 0; d < D; d++)
+      {
+         bg.b[q*D + d] = B[q + Q*d];
+         bg.g[q*D + d] = G ? G[q + Q*d] : 0.0;
+      }
+   return 0;
+}
+
+template <typename K>
+static int set_lds(K kern, size_t lds)
+{
+   MFA_REQUIRE(lds <= 160*1024, "setup kernel needs %zu B of LDS (> 160 KiB)", lds);
+   if (lds > 64*1024)
+   {
+      return check_hip(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                       "hipFuncSetAttribute");
+   }
+   return 0;
+}
+
+} // namespace mfa
+
+using namespace mfa;
+
+extern "C" int mfem_amd_geom_jacobians_3d(int Dn, int Q1D, int64_t ne, const double *Bn,
+                                          const double *Gn, const double *nodesE, double *J,
+                                          void *stream)
+{
+   if (ne == 0) { return 0; }
+   MFA_REQUIRE(ne > 0 && ne < 2147483647 && nodesE && J && Gn, "geom_jacobians_3d: bad arguments");
+   BasisT<MAX_DQ> bg;
+   if (int rc = fill_basis_dyn(bg, Dn, Q1D, Bn, Gn)) { return rc; }
+   const size_t lds = jac_lds_bytes(Dn, Q1D);
+   if (int rc = set_lds(k_jacobians, lds)) { return rc; }
+   k_jacobians<<<dim3((unsigned)ne), dim3(256), lds, as_stream(stream)>>>(Dn, Q1D, bg, nodesE, J);
+   MFA_CHECK_LAUNCH("k_jacobians");
+   return 0;
+}
+
+extern "C" int mfem_amd_geom_det_3d(int Q1D, int64_t ne, const double *J, double *detJ,
+                                    void *stream)
+{
+   const int64_t n = ne*Q1D*Q1D*Q1D;
+   if (n == 0) { return 0; }
+   MFA_REQUIRE(n > 0 && J && detJ, "geom_det_3d: bad arguments");
+   k_det<<<dim3((unsigned)((n + 255)/256)), dim3(256), 0, as_stream(stream)>>>(n, Q1D*Q1D*Q1D, J, detJ);
+   MFA_CHECK_LAUNCH("k_det");
+   return 0;
+}
+
+extern "C" int mfem_amd_diffusion_setup_3d(int Q1D, int coeffDim, int64_t ne, const double *W,
+                                           const double *J, const double *C, int const_c,
+                                           double *D, void *stream)
+{
+   const int64_t n = ne*Q1D*Q1D*Q1D;
+   if (n == 0) { return 0; }
+   MFA_REQUIRE(Q1D >= 1 && Q1D <= MAX_Q1D, "diffusion_setup_3d: Q1D = %d out of range", Q1D);
+   MFA_REQUIRE(coeffDim == 1 || coeffDim == 3,
+               "diffusion_setup_3d: coeffDim = %d (matrix coefficients are not supported)", coeffDim);
+   MFA_REQUIRE(n > 0 && W && J && C && D, "diffusion_setup_3d: bad arguments");
+   const double *dW = W;
+   k_diffusion_setup<<<dim3((unsigned)((n + 255)/256)), dim3(256), 0, as_stream(stream)>>>(
+      n, Q1D*Q1D*Q1D, coeffDim, dW, J, C, const_c, D);
+   MFA_CHECK_LAUNCH("k_diffusion_setup");
+   return 0;
+}
+
+extern "C" int mfem_amd_mass_setup_3d(int Q1D, int64_t ne, const double *W, const double *detJ,
+                                      const double *C, int const_c, double *D, void *stream)
+{
+   const int64_t n = ne*Q1D*Q1D*Q1D;
+   if (n == 0) { return 0; }
+   MFA_REQUIRE(Q1D >= 1 && Q1D <= MAX_Q1D, "mass_setup_3d: Q1D = %d out of range", Q1D);
+   MFA_REQUIRE(n > 0 && W && detJ && C && D, "mass_setup_3d: bad arguments");
+   const double *dW = W;
+   k_mass_setup<<<dim3((unsigned)((n + 255)/256)), dim3(256), 0, as_stream(stream)>>>(
+      n, Q1D*Q1D*Q1D, dW, detJ, C, const_c, D);
+   MFA_CHECK_LAUNCH("k_mass_setup");
+   return 0;
+}
+
+extern "C" int mfem_amd_pa_setup_from_nodes_3d(int kind, int Dn, int Q1D, int coeffDim,
+                                               int64_t ne, const double *Bn, const double *Gn,
+                                               const double *W, const double *nodesE,
+                                               const double *C, int const_c, double *D,
+                                               double *detJ_out, void *stream)
+{
+   if (ne == 0) { return 0; }
+   MFA_REQUIRE(kind == 0 || kind == 1, "pa_setup_from_nodes_3d: kind must be 0 or 1");
+   MFA_REQUIRE(coeffDim == 1 || (kind == 1 && coeffDim == 3), "pa_setup_from_nodes_3d: coeffDim = %d unsupported", coeffDim);
+   MFA_REQUIRE(ne > 0 && ne < 2147483647 && W && nodesE && C && D && Gn, "pa_setup_from_nodes_3d: bad arguments");
+   BasisT<MAX_DQ> bg;
+   if (int rc = fill_basis_dyn(bg, Dn, Q1D, Bn, Gn)) { return rc; }
+   const double *dW = W;
+   const size_t lds = jac_lds_bytes(Dn, Q1D);
+   if (int rc = set_lds(k_setup_from_nodes, lds)) { return rc; }
+   k_setup_from_nodes<<<dim3((unsigned)ne), dim3(256), lds, as_stream(stream)>>>(
+      kind, Dn, Q1D, coeffDim, bg, dW, nodesE, C, const_c, D, detJ_out);
+   MFA_CHECK_LAUNCH("k_setup_from_nodes");
+   return 0;
+}
+
+extern "C" int mfem_amd_pa_diffusion_diag_3d(int D1D, int Q1D, int64_t ne, int symmetric,
+                                             const double *B, const double *G, const double *D,
+                                             double *diagE, void *stream)
+{
+   if (ne == 0) { return 0; }
+   MFA_REQUIRE(symmetric, "pa_diffusion_diag_3d: only the symmetric (6-component) D is supported");
+   MFA_REQUIRE(ne > 0 && ne < 2147483647 && D && diagE && G, "pa_diffusion_diag_3d: bad arguments");
+   BasisT<MAX_DQ> bg;
+   if (int rc = fill_basis_dyn(bg, D1D, Q1D, B, G)) { return rc; }
+   const size_t lds = sizeof(double)*(size_t)(2*Q1D*D1D + Q1D*Q1D*D1D + Q1D*D1D*D1D);
+   if (int rc = set_lds(k_diag<1>, lds)) { return rc; }
+   k_diag<1><<<dim3((unsigned)ne), dim3(256), lds, as_stream(stream)>>>(D1D, Q1D, bg, D, diagE);
+   MFA_CHECK_LAUNCH("k_diag<diffusion>");
+   return 0;
+}
+
+extern "C" int mfem_amd_pa_mass_diag_3d(int D1D, int Q1D, int64_t ne, const double *B,
+                                        const double *D, double *diagE, void *stream)
+{
+   if (ne == 0) { return 0; }
+   MFA_REQUIRE(ne > 0 && ne < 2147483647 && D && diagE, "pa_mass_diag_3d: bad arguments");
+   BasisT<MAX_DQ> bg;
+   if (int rc = fill_basis_dyn(bg, D1D, Q1D, B, nullptr)) { return rc; }
+   const size_t lds = sizeof(double)*(size_t)(2*Q1D*D1D + Q1D*Q1D*D1D + Q1D*D1D*D1D);
+   if (int rc = set_lds(k_diag<0>, lds)) { return rc; }
+   k_diag<0><<<dim3((unsigned)ne), dim3(256), lds, as_stream(stream)>>>(D1D, Q1D, bg, D, diagE);
+   MFA_CHECK_LAUNCH("k_diag<mass>");
+   return 0;
+}

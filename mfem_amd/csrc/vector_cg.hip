@@ -1,0 +1,406 @@
+// Vector kernels, deterministic reductions and the device-resident Jacobi-PCG (gfx950).
+//
+// Replaces linalg/vector.cpp:203-240 (operator=), :436-473 (add), :570 (subtract),
+// :1079-1152 (operator*) + general/reducers.hpp:451-593 (reduce), linalg/solvers.cpp:401-453
+// (OperatorJacobiSmoother) and linalg/solvers.cpp:869-1050 (CGSolver::Mult).
+//
+// The reference runs one kernel per BLAS-1 call (22 vector passes per PCG iteration) and
+// synchronises the host twice per iteration to read the dot products.  Here one iteration
+// is: kernel A {x += alpha d; r -= alpha z; z = dinv.r; partial r.z}, a one-workgroup
+// scalar kernel, kernel B {d = z + beta d}, the fused gather+apply kernel, the
+// transpose-gather kernel with the d.Ad partial folded into its epilogue, and a second
+// scalar kernel -- 12 vector passes; alpha/beta/(Br,r) and the stop flag stay on the device.
+// All reductions have a fixed shape that depends on n only (wavefront shuffles, fixed-order
+// LDS combine, fixed-order final pass), so repeated runs are bit-identical.
+#include "common.h"
+#include <cmath>
+#include <vector>
+
+namespace mfa
+{
+
+constexpr int RED_BLOCKS_MAX = 1024;       // partials per reduction
+
+int pa_apply_L2E(int kind, int D, int Q, int64_t ne, const double *B, const double *G,
+                 const double *Dq, const int *gmap, const double *x, double *yE, hipStream_t s);
+int scatter_dot(int64_t ndofs, const int *offsets, const int *indices, const double *xE,
+                double *y, const unsigned char *marker, const double *xin, const double *w,
+                double *partials, int nblocks, const int *skip, hipStream_t s);
+
+static inline int red_blocks(int64_t n)
+{
+   int64_t nb = (n + 256*8 - 1)/(256*8);     // >= 8 elements per thread before adding blocks
+   if (nb < 1) { nb = 1; }
+   if (nb > RED_BLOCKS_MAX) { nb = RED_BLOCKS_MAX; }
+   return (int)nb;
+}
+
+__global__ void __launch_bounds__(256)
+k_axpby(const int64_t n, const double a, const double *x, const double b, const double *y,
+        double *z)
+{
+   for (int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x; i < n; i += (int64_t)gridDim.x*256)
+   {
+      z[i] = y ? a*x[i] + b*y[i] : a*x[i];
+   }
+}
+
+__global__ void __launch_bounds__(256)
+k_fill(const int64_t n, const double v, double *__restrict__ x)
+{
+   for (int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x; i < n; i += (int64_t)gridDim.x*256) { x[i] = v; }
+}
+
+__global__ void __launch_bounds__(256)
+k_dot_partial(const int64_t n, const double *__restrict__ x, const double *__restrict__ y,
+              double *__restrict__ partials)
+{
+   __shared__ double s4[4];
+   double acc = 0.0;
+   for (int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x; i < n; i += (int64_t)gridDim.x*256)
+   {
+      acc += x[i]*y[i];
+   }
+   const double r = block_sum_256(acc, s4);
+   if (threadIdx.x == 0) { partials[blockIdx.x] = r; }
+}
+
+// Sum of nb (<= 1024) partials by one workgroup, fixed order: thread t adds partials
+// t, t+256, ... then the fixed block tree.
+__device__ __forceinline__ double final_sum(const double *partials, const int nb, double *s4)
+{
+   double acc = 0.0;
+   for (int i = threadIdx.x; i < nb; i += 256) { acc += partials[i]; }
+   return block_sum_256(acc, s4);
+}
+
+__global__ void __launch_bounds__(256)
+k_dot_final(const int nb, const double *__restrict__ partials, double *__restrict__ result)
+{
+   __shared__ double s4[4];
+   const double r = final_sum(partials, nb, s4);
+   if (threadIdx.x == 0) { *result = r; }
+}
+
+__global__ void __launch_bounds__(256)
+k_jacobi_setup(const int64_t n, const double *__restrict__ diag, const double damping,
+               double *__restrict__ dinv)
+{
+   for (int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x; i < n; i += (int64_t)gridDim.x*256)
+   {
+      dinv[i] = damping/diag[i];
+   }
+}
+
+__global__ void __launch_bounds__(256)
+k_mul(const int64_t n, const double *__restrict__ a, const double *__restrict__ b,
+      double *__restrict__ z)
+{
+   for (int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x; i < n; i += (int64_t)gridDim.x*256)
+   {
+      z[i] = a[i]*b[i];
+   }
+}
+
+// ---- device-resident PCG state -------------------------------------------------------
+struct PcgState
+{
+   double nom, den, betanom, alpha, beta, r0, nom0;
+   int iter;        // iterations completed (CGSolver final_iter when done)
+   int done;        // stop flag: kernels become no-ops
+   int converged;
+   int max_iter;
+   double rel_tol, abs_tol;
+};
+
+// r = b; x = 0; z = dinv.r (or r); d = z; partial d.r
+__global__ void __launch_bounds__(256)
+k_pcg_init(const int64_t n, const double *__restrict__ b, const double *__restrict__ dinv,
+           double *__restrict__ x, double *__restrict__ r, double *__restrict__ d,
+           double *__restrict__ partials)
+{
+   __shared__ double s4[4];
+   double acc = 0.0;
+   for (int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x; i < n; i += (int64_t)gridDim.x*256)
+   {
+      const double ri = b[i];
+      const double zi = dinv ? dinv[i]*ri : ri;
+      x[i] = 0.0; r[i] = ri; d[i] = zi;
+      acc += zi*ri;
+   }
+   const double s = block_sum_256(acc, s4);
+   if (threadIdx.x == 0) { partials[blockIdx.x] = s; }
+}
+
+// nom0 = nom = (d, r); r0; immediate-convergence / indefinite checks
+// (linalg/solvers.cpp:895-928).
+__global__ void __launch_bounds__(256)
+k_pcg_init_scalars(const int nb, const double *__restrict__ partials, PcgState *st,
+                   double *__restrict__ hist)
+{
+   __shared__ double s4[4];
+   const double nom = final_sum(partials, nb, s4);
+   if (threadIdx.x == 0)
+   {
+      st->nom = st->nom0 = st->betanom = nom;
+      st->iter = 0; st->converged = 0; st->done = 0;
+      if (hist) { hist[0] = nom; }
+      const double r0 = fmax(nom*st->rel_tol*st->rel_tol, st->abs_tol*st->abs_tol);
+      st->r0 = r0;
+      if (!(nom >= 0.0)) { st->done = 1; }                    // negative or NaN
+      else if (nom <= r0) { st->converged = 1; st->done = 1; }
+   }
+}
+
+// den = (d, A d) after the first/each operator application (linalg/solvers.cpp:931-949,
+// 1010-1025); nom <- betanom at the end of an iteration.
+__global__ void __launch_bounds__(256)
+k_pcg_den_scalars(const int nb, const double *__restrict__ partials, PcgState *st, const int first)
+{
+   __shared__ double s4[4];
+   if (st->done) { return; }
+   const double den = final_sum(partials, nb, s4);
+   if (threadIdx.x == 0)
+   {
+      st->den = den;
+      if (!first) { st->nom = st->betanom; }
+      if (den == 0.0 || den != den)                           // (linalg/solvers.cpp:940-948, 1019-1023)
+      {
+         st->done = 1;
+         if (!first) { st->iter += 1; }                       // the reference has already done ++i
+      }
+      else { st->alpha = st->nom/den; }
+   }
+}
+
+// kernel A: x += alpha d; r -= alpha z; z = dinv.r (or r); partial (r, z)
+__global__ void __launch_bounds__(256)
+k_pcg_update(const int64_t n, const PcgState *__restrict__ st, const double *__restrict__ dinv,
+             const double *__restrict__ d, double *__restrict__ x, double *__restrict__ r,
+             double *__restrict__ z, double *__restrict__ partials)
+{
+   __shared__ double s4[4];
+   if (st->done) { return; }
+   const double alpha = st->alpha;
+   double acc = 0.0;
+   for (int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x; i < n; i += (int64_t)gridDim.x*256)
+   {
+      x[i] = x[i] + alpha*d[i];
+      const double ri = r[i] + (-alpha)*z[i];
+      const double zi = dinv ? dinv[i]*ri : ri;
+      r[i] = ri; z[i] = zi;
+      acc += ri*zi;
+   }
+   const double s = block_sum_256(acc, s4);
+   if (threadIdx.x == 0) { partials[blockIdx.x] = s; }
+}
+
+// betanom, convergence test, iteration count, beta (linalg/solvers.cpp:963-1000).
+__global__ void __launch_bounds__(256)
+k_pcg_beta_scalars(const int nb, const double *__restrict__ partials, PcgState *st,
+                   double *__restrict__ hist)
+{
+   __shared__ double s4[4];
+   if (st->done) { return; }
+   const double betanom = final_sum(partials, nb, s4);
+   if (threadIdx.x == 0)
+   {
+      const int i = st->iter + 1;        // the iteration whose update just ran
+      st->betanom = betanom;
+      if (hist) { hist[i] = betanom; }
+      if (!(betanom >= 0.0)) { st->iter = i; st->done = 1; }
+      else if (betanom <= st->r0) { st->iter = i; st->converged = 1; st->done = 1; }
+      else if (i + 1 > st->max_iter) { st->iter = st->max_iter; st->done = 1; }
+      else { st->iter = i; st->beta = betanom/st->nom; }
+   }
+}
+
+// kernel B: d = z + beta d
+__global__ void __launch_bounds__(256)
+k_pcg_dir(const int64_t n, const PcgState *__restrict__ st, const double *__restrict__ z,
+          double *__restrict__ d)
+{
+   if (st->done) { return; }
+   const double beta = st->beta;
+   for (int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x; i < n; i += (int64_t)gridDim.x*256)
+   {
+      d[i] = z[i] + beta*d[i];
+   }
+}
+
+static inline unsigned stream_grid(int64_t n)
+{
+   int64_t nb = (n + 255)/256;
+   if (nb > 256*8) { nb = 256*8; }        // 8 workgroups per CU, grid-stride the rest
+   if (nb < 1) { nb = 1; }
+   return (unsigned)nb;
+}
+
+} // namespace mfa
+
+using namespace mfa;
+
+extern "C" int mfem_amd_vec_axpby(int64_t n, double a, const double *x, double b,
+                                  const double *y, double *z, void *stream)
+{
+   if (n == 0) { return 0; }
+   MFA_REQUIRE(n > 0 && x && z && (y || b == 0.0), "vec_axpby: bad arguments");
+   k_axpby<<<dim3(stream_grid(n)), dim3(256), 0, as_stream(stream)>>>(n, a, x, b, b == 0.0 ? nullptr : y, z);
+   MFA_CHECK_LAUNCH("k_axpby");
+   return 0;
+}
+
+extern "C" int mfem_amd_vec_fill(int64_t n, double value, double *x, void *stream)
+{
+   if (n == 0) { return 0; }
+   MFA_REQUIRE(n > 0 && x, "vec_fill: bad arguments");
+   k_fill<<<dim3(stream_grid(n)), dim3(256), 0, as_stream(stream)>>>(n, value, x);
+   MFA_CHECK_LAUNCH("k_fill");
+   return 0;
+}
+
+extern "C" int64_t mfem_amd_reduce_workspace_bytes(void)
+{
+   return (int64_t)sizeof(double)*RED_BLOCKS_MAX;
+}
+
+extern "C" int mfem_amd_vec_dot(int64_t n, const double *x, const double *y, double *result,
+                                void *ws, void *stream)
+{
+   MFA_REQUIRE(n >= 0 && result && ws && (n == 0 || (x && y)), "vec_dot: bad arguments");
+   hipStream_t s = as_stream(stream);
+   const int nb = red_blocks(n);
+   k_dot_partial<<<dim3(nb), dim3(256), 0, s>>>(n, x, y, (double*)ws);
+   MFA_CHECK_LAUNCH("k_dot_partial");
+   k_dot_final<<<dim3(1), dim3(256), 0, s>>>(nb, (const double*)ws, result);
+   MFA_CHECK_LAUNCH("k_dot_final");
+   return 0;
+}
+
+extern "C" int mfem_amd_jacobi_setup(int64_t n, const double *diag, double damping,
+                                     int64_t ness, const int *ess, double *dinv, void *stream)
+{
+   if (n == 0) { return 0; }
+   MFA_REQUIRE(n > 0 && diag && dinv && (ness == 0 || ess), "jacobi_setup: bad arguments");
+   k_jacobi_setup<<<dim3(stream_grid(n)), dim3(256), 0, as_stream(stream)>>>(n, diag, damping, dinv);
+   MFA_CHECK_LAUNCH("k_jacobi_setup");
+   if (ness > 0) { return mfem_amd_set_subvector(ness, ess, nullptr, damping, dinv, stream); }
+   return 0;
+}
+
+extern "C" int mfem_amd_jacobi_apply(int64_t n, const double *dinv, const double *r, double *z,
+                                     void *stream)
+{
+   if (n == 0) { return 0; }
+   MFA_REQUIRE(n > 0 && dinv && r && z, "jacobi_apply: bad arguments");
+   k_mul<<<dim3(stream_grid(n)), dim3(256), 0, as_stream(stream)>>>(n, dinv, r, z);
+   MFA_CHECK_LAUNCH("k_mul");
+   return 0;
+}
+
+// y = A x for the constrained PA operator; optionally the partial sums of (w, y).
+static int constrained_mult(const mfem_amd_pa_operator *op, const double *x, double *y,
+                            const double *w, double *partials, int nb, const int *skip,
+                            hipStream_t s)
+{
+   const bool ess = op->ness > 0;
+   const int *gm = ess ? op->masked_gather_map : op->gather_map;
+   MFA_REQUIRE(gm, "pa operator: %s is NULL", ess ? "masked_gather_map" : "gather_map");
+   MFA_REQUIRE(!ess || op->ess_marker, "pa operator: ess_marker is NULL");
+   MFA_REQUIRE(op->yE && op->offsets && op->indices && op->pa_data, "pa operator: null array");
+   // NOTE: the element kernel is not gated by `skip`: after convergence it only rewrites
+   // the work E-vector, and the gated transpose-gather leaves y untouched.
+   if (int rc = pa_apply_L2E(op->kind, op->D1D, op->Q1D, op->ne, op->B, op->G, op->pa_data, gm, x, op->yE, s)) { return rc; }
+   return scatter_dot(op->ndofs, op->offsets, op->indices, op->yE, y, ess ? op->ess_marker : nullptr,
+                      x, w, partials, nb, skip, s);
+}
+
+extern "C" int mfem_amd_pa_constrained_mult(const mfem_amd_pa_operator *op, const double *x,
+                                            double *y, void *stream)
+{
+   MFA_REQUIRE(op && x && y, "pa_constrained_mult: bad arguments");
+   MFA_REQUIRE(x != y, "pa_constrained_mult: x and y must not alias");
+   const unsigned nb = (unsigned)((op->ndofs + 255)/256);
+   if (op->ndofs == 0) { return 0; }
+   return constrained_mult(op, x, y, nullptr, nullptr, (int)nb, nullptr, as_stream(stream));
+}
+
+static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1)/a*a; }
+
+extern "C" int64_t mfem_amd_pcg_workspace_bytes(int64_t n, int max_iter)
+{
+   // r, d, z | partials | hist | state
+   return 3*align_up(n*8, 256) + align_up(RED_BLOCKS_MAX*8, 256) +
+          align_up(((int64_t)max_iter + 2)*8, 256) + 256;
+}
+
+extern "C" int mfem_amd_pcg_pa(const mfem_amd_pa_operator *op, const double *dinv,
+                               const double *b, double *x, double rel_tol, double abs_tol,
+                               int max_iter, int check_every, void *workspace,
+                               mfem_amd_pcg_result *result, double *hist, void *stream)
+{
+   MFA_REQUIRE(op && b && x && workspace && result, "pcg_pa: bad arguments");
+   MFA_REQUIRE(max_iter >= 0, "pcg_pa: max_iter < 0");
+   if (check_every < 1) { check_every = 1; }
+   hipStream_t s = as_stream(stream);
+   const int64_t n = op->ndofs;
+   char *ws = (char*)workspace;
+   double *r = (double*)ws; ws += align_up(n*8, 256);
+   double *d = (double*)ws; ws += align_up(n*8, 256);
+   double *z = (double*)ws; ws += align_up(n*8, 256);
+   double *partials = (double*)ws; ws += align_up(RED_BLOCKS_MAX*8, 256);
+   double *dhist = (double*)ws; ws += align_up(((int64_t)max_iter + 2)*8, 256);
+   PcgState *st = (PcgState*)ws;
+
+   PcgState h = {};
+   h.max_iter = max_iter; h.rel_tol = rel_tol; h.abs_tol = abs_tol;
+   if (int rc = check_hip(hipMemcpyAsync(st, &h, sizeof h, hipMemcpyHostToDevice, s), "hipMemcpyAsync(state)")) { return rc; }
+
+   const int nb = red_blocks(n);
+   const unsigned sg = stream_grid(n);
+   k_pcg_init<<<dim3(nb), dim3(256), 0, s>>>(n, b, dinv, x, r, d, partials);
+   MFA_CHECK_LAUNCH("k_pcg_init");
+   k_pcg_init_scalars<<<dim3(1), dim3(256), 0, s>>>(nb, partials, st, dhist);
+   MFA_CHECK_LAUNCH("k_pcg_init_scalars");
+   // z = A d; den = (z, d)
+   if (int rc = constrained_mult(op, d, z, d, partials, nb, &st->done, s)) { return rc; }
+   k_pcg_den_scalars<<<dim3(1), dim3(256), 0, s>>>(nb, partials, st, 1);
+   MFA_CHECK_LAUNCH("k_pcg_den_scalars");
+
+   // The reference's loop body runs at least once, even for max_iter == 0.
+   const int total = max_iter > 0 ? max_iter : 1;
+   PcgState cur;
+   int launched = 0;
+   while (true)
+   {
+      if (int rc = check_hip(hipMemcpyAsync(&cur, st, sizeof cur, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(poll)")) { return rc; }
+      if (int rc = check_hip(hipStreamSynchronize(s), "hipStreamSynchronize")) { return rc; }
+      if (cur.done || launched >= total) { break; }
+      int batch = check_every;
+      if (batch > total - launched) { batch = total - launched; }
+      for (int k = 0; k < batch; k++)
+      {
+         k_pcg_update<<<dim3(nb), dim3(256), 0, s>>>(n, st, dinv, d, x, r, z, partials);
+         k_pcg_beta_scalars<<<dim3(1), dim3(256), 0, s>>>(nb, partials, st, dhist);
+         k_pcg_dir<<<dim3(sg), dim3(256), 0, s>>>(n, st, z, d);
+         MFA_CHECK_LAUNCH("pcg iteration kernels");
+         if (int rc = constrained_mult(op, d, z, d, partials, nb, &st->done, s)) { return rc; }
+         k_pcg_den_scalars<<<dim3(1), dim3(256), 0, s>>>(nb, partials, st, 0);
+         MFA_CHECK_LAUNCH("k_pcg_den_scalars");
+      }
+      launched += batch;
+   }
+   // Reference bookkeeping (linalg/solvers.cpp:952-953,995-998): if the loop ran out of
+   // iterations without converging, final_iter = max_iter.
+   result->iterations = cur.done ? cur.iter : max_iter;
+   result->converged = cur.converged;
+   result->initial_nom = cur.nom0;
+   result->final_nom = cur.betanom;
+   if (hist)
+   {
+      const int cnt = result->iterations + 1;
+      if (int rc = check_hip(hipMemcpyAsync(hist, dhist, sizeof(double)*cnt, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(hist)")) { return rc; }
+      if (int rc = check_hip(hipStreamSynchronize(s), "hipStreamSynchronize")) { return rc; }
+   }
+   return 0;
+}

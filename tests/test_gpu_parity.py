@@ -1,0 +1,185 @@
+"""-m gpu parity tests: the HIP path, called through the C ABI (include/mfem_amd.h), against
+(a) arrays produced by the reference itself (tests/golden) and (b) the CPU oracle on the
+same inputs.  Integer/index work and the E->L sum: bit-exact.  Floating point: 1e-12
+relative (north_star), tolerance written at each assert."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from conftest import golden_cases, load_case, splitmix  # noqa: E402
+
+CASES = golden_cases()
+TOL = 1e-12
+
+
+def relerr(a, b):
+    return np.max(np.abs(a - b))/max(np.max(np.abs(b)), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def gh():
+    import gpu_helpers
+    from mfem_amd import capi
+    capi.call("mfem_amd_init", 0)
+    return gpu_helpers
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_restriction(gh, name):
+    from mfem_amd import capi
+    c = load_case(name)
+    nd = c["D1D"]**3
+    x, gm = gh.dev(c["x"]), gh.dev(c["gather_map"], np.int32)
+    xE = gh.zeros(c["NE"]*nd)
+    capi.call("mfem_amd_restrict_gather", c["NE"]*nd, gh.ptr(gm), gh.ptr(x), gh.ptr(xE), None)
+    assert np.array_equal(gh.host(xE), c["xE"])                       # bit-exact
+    # E->L: same summation order as the reference -> bit-exact on the reference's own yE
+    off, ind, yE = gh.dev(c["offsets"], np.int32), gh.dev(c["indices"], np.int32), gh.dev(c["yE"])
+    y = gh.zeros(c["ndofs"])
+    capi.call("mfem_amd_restrict_scatter", c["ndofs"], gh.ptr(off), gh.ptr(ind), gh.ptr(yE), gh.ptr(y), 0, 0, None)
+    assert np.array_equal(gh.host(y), c["y"])                         # bit-exact
+    capi.call("mfem_amd_restrict_scatter", c["ndofs"], gh.ptr(off), gh.ptr(ind), gh.ptr(yE), gh.ptr(y), 1, 0, None)
+    assert np.array_equal(gh.host(y), c["y"] + c["y"])
+    dE = gh.dev(c["diagE"])
+    capi.call("mfem_amd_restrict_scatter", c["ndofs"], gh.ptr(off), gh.ptr(ind), gh.ptr(dE), gh.ptr(y), 0, 1, None)
+    assert np.array_equal(gh.host(y), c["diag"])                      # AbsMultTranspose, bit-exact
+    # mesh nodes (vdim = 3)
+    ndn = c["nodes_D1D"]**3
+    nodes, ngm = gh.dev(c["nodes"]), gh.dev(c["nodes_gather_map"], np.int32)
+    nE = gh.zeros(c["NE"]*ndn*3)
+    capi.call("mfem_amd_restrict_gather_vdim", c["NE"]*ndn, ndn, 3, c["nodes_byvdim"], c["nodes_ndofs"],
+              gh.ptr(ngm), gh.ptr(nodes), gh.ptr(nE), None)
+    assert np.array_equal(gh.host(nE), c["nodes_E"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_geometry_and_setup(gh, name):
+    from mfem_amd import capi
+    c = load_case(name)
+    Q, NE, Dn = c["Q1D"], c["NE"], c["nodes_D1D"]
+    nE, W, coeff = gh.dev(c["nodes_E"]), gh.dev(c["W"]), gh.dev(c["coeff"])
+    const_c = int(len(c["coeff"]) == 1)
+    J, detJ = gh.zeros(9*Q**3*NE), gh.zeros(Q**3*NE)
+    capi.call("mfem_amd_geom_jacobians_3d", Dn, Q, NE, gh.hB(c["nodes_B"]), gh.hB(c["nodes_G"]), gh.ptr(nE), gh.ptr(J), None)
+    capi.call("mfem_amd_geom_det_3d", Q, NE, gh.ptr(J), gh.ptr(detJ), None)
+    if "J" in c:
+        assert relerr(gh.host(J), c["J"]) < 1e-13
+    assert relerr(gh.host(detJ), c["detJ"]) < TOL
+    ncomp = 6 if c["kind"] else 1
+    D1, D2, det2 = gh.zeros(ncomp*Q**3*NE), gh.zeros(ncomp*Q**3*NE), gh.zeros(Q**3*NE)
+    if c["kind"]:
+        capi.call("mfem_amd_diffusion_setup_3d", Q, 1, NE, gh.ptr(W), gh.ptr(J), gh.ptr(coeff), const_c, gh.ptr(D1), None)
+    else:
+        capi.call("mfem_amd_mass_setup_3d", Q, NE, gh.ptr(W), gh.ptr(detJ), gh.ptr(coeff), const_c, gh.ptr(D1), None)
+    assert relerr(gh.host(D1), c["pa_data"]) < TOL
+    capi.call("mfem_amd_pa_setup_from_nodes_3d", c["kind"], Dn, Q, 1, NE, gh.hB(c["nodes_B"]), gh.hB(c["nodes_G"]),
+              gh.ptr(W), gh.ptr(nE), gh.ptr(coeff), const_c, gh.ptr(D2), gh.ptr(det2), None)
+    assert relerr(gh.host(D2), c["pa_data"]) < TOL
+    assert relerr(gh.host(det2), c["detJ"]) < TOL
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_apply_and_diag(gh, name):
+    from mfem_amd import capi
+    import oracle_lib as orc
+    c = load_case(name)
+    D1, Q1, NE, nd = c["D1D"], c["Q1D"], c["NE"], c["D1D"]**3
+    B, G = gh.hB(c["B"]), gh.hB(c["G"])
+    pa, xE = gh.dev(c["pa_data"]), gh.dev(c["xE"])
+    # AddMultPA semantics: yE += A xE, starting from a non-zero yE
+    y0 = splitmix(7, NE*nd)
+    yE = gh.dev(y0)
+    if c["kind"]:
+        capi.call("mfem_amd_pa_diffusion_apply_3d", D1, Q1, NE, 1, B, G, gh.ptr(pa), gh.ptr(xE), gh.ptr(yE), None)
+    else:
+        capi.call("mfem_amd_pa_mass_apply_3d", D1, Q1, NE, B, gh.ptr(pa), gh.ptr(xE), gh.ptr(yE), None)
+    got = gh.host(yE) - y0
+    scale = np.max(np.abs(c["yE"]))
+    assert np.max(np.abs(got - c["yE"]))/scale < 1e-12 + 4*np.finfo(float).eps*np.max(np.abs(y0))/scale
+    # fused L->E + deterministic E->L against the reference's L->L action
+    op = gh.DeviceOperator(c)
+    y = gh.host(op.apply_L2L(gh.dev(c["x"])))
+    assert relerr(y, c["y"]) < TOL                                     # vs the reference
+    assert relerr(gh.host(op.yE), c["yE"]) < TOL
+    oop = orc.Operator(c["kind"], D1, Q1, NE, c["ndofs"], c["B"], c["G"], c["pa_data"], c["gather_map"],
+                       c["offsets"], c["indices"])
+    assert relerr(y, oop.mult(c["x"])) < TOL                           # vs the CPU oracle
+    # element and L diagonals
+    dE = gh.zeros(NE*nd)
+    if c["kind"]:
+        capi.call("mfem_amd_pa_diffusion_diag_3d", D1, Q1, NE, 1, B, G, gh.ptr(pa), gh.ptr(dE), None)
+    else:
+        capi.call("mfem_amd_pa_mass_diag_3d", D1, Q1, NE, B, gh.ptr(pa), gh.ptr(dE), None)
+    assert relerr(gh.host(dE), c["diagE"]) < TOL
+    assert capi.lib.mfem_amd_has_specialization(c["kind"], D1, Q1) == int(Q1 in (D1, D1 + 1) and 2 <= D1 <= 9)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_constrained_operator_and_pcg(gh, name):
+    from mfem_amd import capi
+    c = load_case(name)
+    n, ess = c["ndofs"], c["ess_tdof"]
+    op = gh.DeviceOperator(c, ess)
+    y = gh.host(op.constrained_mult(gh.dev(c["x"])))
+    assert relerr(y, c["y_constrained"]) < TOL
+    assert np.array_equal(y[ess], c["x"][ess])
+    # Jacobi from the L-diagonal
+    diag, dinv = gh.dev(c["diag"]), gh.zeros(n)
+    capi.call("mfem_amd_jacobi_setup", n, gh.ptr(diag), 1.0, len(ess), gh.ptr(op.ess), gh.ptr(dinv), None)
+    z = gh.zeros(n)
+    capi.call("mfem_amd_jacobi_apply", n, gh.ptr(dinv), gh.ptr(gh.dev(c["x"])), gh.ptr(z), None)
+    assert relerr(gh.host(z), c["jacobi_x"]) < TOL
+    # PCG: identical iteration count, solution to 1e-9 (CG amplifies rounding by cond(A)),
+    # (B r, r) history to the 6 digits the reference prints
+    rel_tol = 1e-10 if c["kind"] == 0 else 1e-6
+    b = gh.dev(c["B_rhs"])
+    for check_every in (1, 5):
+        X, res, hist = op.pcg(b, dinv, rel_tol, check_every=check_every)
+        assert res.iterations == c["cg_iters"] and bool(res.converged) == bool(c["cg_converged"])
+        ref = c["cg_hist"]
+        assert len(hist) == len(ref)
+        big = ref > 1e-20*ref[0]
+        assert np.max(np.abs(hist[big] - ref[big])/ref[big]) < 1e-5
+        assert relerr(gh.host(X), c["X"]) < 1e-9
+    # bit-reproducible across runs and across check_every (no-op kernels after convergence)
+    X1, _, h1 = op.pcg(b, dinv, rel_tol, check_every=1)
+    X2, _, h2 = op.pcg(b, dinv, rel_tol, check_every=7)
+    assert np.array_equal(gh.host(X1), gh.host(X2)) and np.array_equal(h1, h2)
+
+
+def test_vector_kernels(gh):
+    from mfem_amd import capi
+    for n in (1, 255, 4099, 1_000_003):
+        a, b = splitmix(3, n) - 0.5, splitmix(4, n) - 0.25
+        da, db, dz = gh.dev(a), gh.dev(b), gh.zeros(n)
+        capi.call("mfem_amd_vec_axpby", n, 1.0, gh.ptr(da), -0.75, gh.ptr(db), gh.ptr(dz), None)
+        assert np.array_equal(gh.host(dz), a + (-0.75)*b) or relerr(gh.host(dz), a - 0.75*b) < 1e-15
+        ws = gh.zeros(capi.lib.mfem_amd_reduce_workspace_bytes(), torch.uint8)
+        r1, r2 = gh.zeros(1), gh.zeros(1)
+        capi.call("mfem_amd_vec_dot", n, gh.ptr(da), gh.ptr(db), gh.ptr(r1), gh.ptr(ws), None)
+        capi.call("mfem_amd_vec_dot", n, gh.ptr(da), gh.ptr(db), gh.ptr(r2), gh.ptr(ws), None)
+        exact = float(np.dot(a.astype(np.longdouble), b.astype(np.longdouble)))
+        assert abs(gh.host(r1)[0] - exact) <= 1e-13*np.sum(np.abs(a*b))
+        assert gh.host(r1)[0] == gh.host(r2)[0]                        # deterministic
+        capi.call("mfem_amd_vec_fill", n, 2.5, gh.ptr(dz), None)
+        assert np.all(gh.host(dz) == 2.5)
+        # aliasing z = x allowed (linalg/vector.cpp:436-473)
+        capi.call("mfem_amd_vec_axpby", n, 1.0, gh.ptr(da), 2.0, gh.ptr(db), gh.ptr(da), None)
+        assert relerr(gh.host(da), a + 2.0*b) < 1e-15
+
+
+def test_errors_are_reported(gh):
+    from mfem_amd import capi
+    x = gh.zeros(8)
+    B = np.zeros(11*15)
+    rc = capi.lib.mfem_amd_pa_mass_apply_3d(11, 15, 1, B, gh.ptr(x), gh.ptr(x), gh.ptr(x), None)
+    assert rc != 0 and b"unsupported" in capi.lib.mfem_amd_last_error()
+    rc = capi.lib.mfem_amd_pa_diffusion_apply_3d(3, 4, 1, 0, B, B, gh.ptr(x), gh.ptr(x), gh.ptr(x), None)
+    assert rc != 0 and b"symmetric" in capi.lib.mfem_amd_last_error()
+    # empty inputs are fine
+    capi.call("mfem_amd_restrict_gather", 0, None, None, None, None)
+    capi.call("mfem_amd_pa_mass_apply_3d", 3, 4, 0, np.zeros(12), gh.ptr(x), gh.ptr(x), gh.ptr(x), None)
