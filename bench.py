@@ -123,14 +123,14 @@ def main():
     ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
     gm, off, ind = t(prob.gather_map), t(prob.offsets), t(prob.indices)
     nodesE, Wd = t(prob.nodes_E), t(W)
-    ncomp = 6 if kind else 1
-    pa = torch.empty(ncomp*Q**3*ne, dtype=torch.float64, device=dev)
+    LAYOUT = 1            # blocked pa_data layout (the product's own AssemblePA + AddMultPA)
+    pa = torch.zeros(capi.lib.mfem_amd_pa_data_size(kind, LAYOUT, Q, ne), dtype=torch.float64, device=dev)
     one = torch.ones(1, dtype=torch.float64, device=dev)
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     capi.call("mfem_amd_pa_setup_from_nodes_3d", kind, 2, Q, 1, ne, Bn, Gn, ptr(Wd), ptr(nodesE), ptr(one), 1,
-              ptr(pa), None, stream)
+              LAYOUT, ptr(pa), None, stream)
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
     del nodesE
@@ -141,7 +141,7 @@ def main():
     yE = torch.empty(ne*D**3, dtype=torch.float64, device=dev)
 
     def l2e():
-        capi.call("mfem_amd_pa_apply_L2E", kind, D, Q, ne, B, G, ptr(pa), ptr(gm), ptr(x), ptr(yE), stream)
+        capi.call("mfem_amd_pa_apply_L2E", kind, LAYOUT, D, Q, ne, B, G, ptr(pa), ptr(gm), ptr(x), ptr(yE), stream)
 
     def e2l():
         capi.call("mfem_amd_restrict_scatter", ndofs, ptr(off), ptr(ind), ptr(yE), ptr(y), 0, 0, stream)
@@ -210,7 +210,7 @@ def main():
         capi.call("mfem_amd_jacobi_setup", ndofs, ptr(diag), 1.0, len(ess), ptr(essd), ptr(dinv), stream)
         del dE
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
-        op = capi.PaOperator(kind, D, Q, ne, ndofs, vp(B), vp(G), ptr(pa), ptr(gm), ptr(masked), ptr(off), ptr(ind),
+        op = capi.PaOperator(kind, LAYOUT, D, Q, ne, ndofs, vp(B), vp(G), ptr(pa), ptr(gm), ptr(masked), ptr(off), ptr(ind),
                              len(ess), ptr(essd), ptr(marker), ptr(yE))
         rhs = torch.rand(ndofs, dtype=torch.float64, generator=g).to(dev)
         rhs[essd.long()] = 0.0

@@ -96,7 +96,19 @@ int mfem_amd_mass_setup_3d(int Q1D, int64_t ne, const double *W, const double *d
 int mfem_amd_pa_setup_from_nodes_3d(int kind, int Dn, int Q1D, int coeffDim, int64_t ne,
                                     const double *Bn, const double *Gn, const double *W,
                                     const double *nodesE, const double *C, int const_c,
-                                    double *D, double *detJ_out, void *stream);
+                                    int pa_layout, double *D, double *detJ_out, void *stream);
+
+/* pa_data layouts.  0: the reference's (q, component, element) (fem/integ/
+ * bilininteg_diffusion_kernels.cpp:257, bilininteg_mass_pa.cpp:72-77) -- what the
+ * dispatch-table level entry points below take, so MFEM's own pa_data can be passed.
+ * 1: blocked for HBM3E, the same doubles permuted so that every load instruction of a
+ * workgroup of the fused kernel reads one contiguous 16-byte-per-lane run (see
+ * mfem_amd/csrc/common.h).  pa_data is a private member of the integrator
+ * (fem/bilininteg.hpp:2213), so its layout is free when both AssemblePA and AddMultPA run
+ * here.  No counterpart in the reference. */
+int64_t mfem_amd_pa_data_size(int kind, int pa_layout, int Q1D, int64_t ne); /* in doubles */
+int mfem_amd_pa_data_to_blocked(int kind, int Q1D, int64_t ne, const double *D,
+                                double *Dblocked, void *stream);
 
 /* ---- PA operator action ---------------------------------------------------------- */
 
@@ -128,9 +140,9 @@ int mfem_amd_pa_mass_diag_3d(int D1D, int Q1D, int64_t ne, const double *B,
  * diffusion.  gather_map entries < 0 here mean "use 0.0" (masked essential dofs, see
  * mfem_amd_mask_gather_map) -- scalar H1 gather maps are never negative in the reference.
  * Follow with mfem_amd_restrict_scatter[_dot] for the E->L sum. */
-int mfem_amd_pa_apply_L2E(int kind, int D1D, int Q1D, int64_t ne, const double *B,
-                          const double *G, const double *D, const int *gather_map,
-                          const double *x, double *yE, void *stream);
+int mfem_amd_pa_apply_L2E(int kind, int pa_layout, int D1D, int Q1D, int64_t ne,
+                          const double *B, const double *G, const double *D,
+                          const int *gather_map, const double *x, double *yE, void *stream);
 
 /* ---- ConstrainedOperator (linalg/operator.cpp:511-646) --------------------------- */
 
@@ -175,6 +187,7 @@ int mfem_amd_jacobi_apply(int64_t n, const double *dinv, const double *r, double
 typedef struct mfem_amd_pa_operator
 {
    int kind;                 /* 0 mass, 1 diffusion */
+   int pa_layout;            /* 0 MFEM layout, 1 blocked (mfem_amd_pa_data_to_blocked) */
    int D1D, Q1D;
    int64_t ne, ndofs;
    const double *B, *G;      /* HOST */

@@ -21,7 +21,7 @@ _hd = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")   # HOST do
 
 class PaOperator(C.Structure):
     """struct mfem_amd_pa_operator"""
-    _fields_ = [("kind", cint), ("D1D", cint), ("Q1D", cint), ("ne", i64), ("ndofs", i64),
+    _fields_ = [("kind", cint), ("pa_layout", cint), ("D1D", cint), ("Q1D", cint), ("ne", i64), ("ndofs", i64),
                 ("B", vp), ("G", vp), ("pa_data", vp), ("gather_map", vp),
                 ("masked_gather_map", vp), ("offsets", vp), ("indices", vp),
                 ("ness", i64), ("ess", vp), ("ess_marker", vp), ("yE", vp)]
@@ -44,12 +44,14 @@ _SIGS = {
     "mfem_amd_geom_det_3d": (cint, [cint, i64, vp, vp, vp]),
     "mfem_amd_diffusion_setup_3d": (cint, [cint, cint, i64, vp, vp, vp, cint, vp, vp]),
     "mfem_amd_mass_setup_3d": (cint, [cint, i64, vp, vp, vp, cint, vp, vp]),
-    "mfem_amd_pa_setup_from_nodes_3d": (cint, [cint, cint, cint, cint, i64, _hd, _hd, vp, vp, vp, cint, vp, vp, vp]),
+    "mfem_amd_pa_setup_from_nodes_3d": (cint, [cint, cint, cint, cint, i64, _hd, _hd, vp, vp, vp, cint, cint, vp, vp, vp]),
+    "mfem_amd_pa_data_size": (i64, [cint, cint, cint, i64]),
+    "mfem_amd_pa_data_to_blocked": (cint, [cint, cint, i64, vp, vp, vp]),
     "mfem_amd_pa_diffusion_apply_3d": (cint, [cint, cint, i64, cint, _hd, _hd, vp, vp, vp, vp]),
     "mfem_amd_pa_mass_apply_3d": (cint, [cint, cint, i64, _hd, vp, vp, vp, vp]),
     "mfem_amd_pa_diffusion_diag_3d": (cint, [cint, cint, i64, cint, _hd, _hd, vp, vp, vp]),
     "mfem_amd_pa_mass_diag_3d": (cint, [cint, cint, i64, _hd, vp, vp, vp]),
-    "mfem_amd_pa_apply_L2E": (cint, [cint, cint, cint, i64, _hd, _hd, vp, vp, vp, vp, vp]),
+    "mfem_amd_pa_apply_L2E": (cint, [cint, cint, cint, cint, i64, _hd, _hd, vp, vp, vp, vp, vp]),
     "mfem_amd_set_marker": (cint, [i64, vp, vp, vp]),
     "mfem_amd_mask_gather_map": (cint, [i64, vp, vp, vp, vp]),
     "mfem_amd_set_subvector": (cint, [i64, vp, vp, dbl, vp, vp]),

@@ -24,6 +24,37 @@ struct BasisT
    double g[N];
 };
 
+// Elements per workgroup of the specialised apply kernels (Q*Q*NBZ ~ 200..256 threads).
+// Also the blocking factor of the HBM-friendly pa_data layout below.
+__host__ __device__ constexpr int nbz_for(int Q)
+{
+   return Q <= 2 ? 32 : Q == 3 ? 16 : Q == 4 ? 16 : Q == 5 ? 10 : Q == 6 ? 7 :
+          Q == 7 ? 5 : Q == 8 ? 4 : Q == 9 ? 3 : 2;
+}
+
+// Blocked pa_data layout (layout 1).  The reference stores D as (q, component, element)
+// (fem/integ/bilininteg_diffusion_kernels.cpp:257); a thread sheet (qx,qy) walking qz then
+// reads Q^2-long segments that start at arbitrary 8-byte offsets.  Layout 1 stores, per
+// batch of NBZ = nbz_for(Q) elements, [qz][component pair][element in batch][qy][qx][2]
+// (diffusion; mass: [qz][element in batch][qy][qx]), so that one load instruction of the
+// whole workgroup reads ONE contiguous, 16-byte-per-lane (mass: 8) run of 4 KB (2 KB).
+// Same doubles, same count (plus padding of the last batch): the algorithmic bytes do
+// not change.
+__host__ __device__ inline int64_t blocked_index(int kind, int Q, int64_t e, int q, int c)
+{
+   const int NBZ = nbz_for(Q), QQ = Q*Q;
+   const int64_t batch = e/NBZ;
+   const int tz = (int)(e % NBZ), qz = q/QQ, qq = q % QQ;
+   if (kind) { return ((((batch*Q + qz)*3 + (c >> 1))*NBZ + tz)*QQ + qq)*2 + (c & 1); }
+   return ((batch*Q + qz)*NBZ + tz)*(int64_t)QQ + qq;
+}
+
+__host__ __device__ inline int64_t blocked_size(int kind, int Q, int64_t ne)
+{
+   const int NBZ = nbz_for(Q);
+   return ((ne + NBZ - 1)/NBZ)*NBZ*(int64_t)(kind ? 6 : 1)*Q*Q*Q;
+}
+
 void set_error(const char *fmt, ...);
 int check_hip(hipError_t e, const char *what);
 bool report_kernels_enabled();

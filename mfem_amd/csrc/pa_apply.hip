@@ -30,17 +30,29 @@
 namespace mfa
 {
 
-constexpr int nbz_for(int Q)
+// Register budget hint (waves per SIMD the kernel should fit, 2nd __launch_bounds__ argument
+// on AMD): at p <= 4 diffusion fits 3 waves/SIMD = 3 resident workgroups per CU.
+constexpr int minw_for(int KIND, int D)
 {
-   return Q <= 2 ? 32 : Q == 3 ? 16 : Q == 4 ? 16 : Q == 5 ? 10 : Q == 6 ? 7 :
-          Q == 7 ? 5 : Q == 8 ? 4 : Q == 9 ? 3 : 2;
+   return KIND ? (D <= 5 ? 3 : D <= 7 ? 2 : 1) : (D <= 7 ? 3 : 2);
 }
 
 // KIND: 0 mass, 1 diffusion.  GATHER: x is an L-vector read through gmap (entries < 0 read
 // as 0.0), else x is an E-vector.  ACCUM: yE += (AddMultPA semantics) else yE =.
-template <int KIND, int D, int Q, int NBZ, bool GATHER, bool ACCUM>
-__global__ void __launch_bounds__(Q*Q*NBZ)
-k_pa_apply(const int64_t ne, const int64_t nblocks, const BasisT<D*Q> bg,
+//
+// Persistent workgroups: the grid is (resident workgroups per CU) x (CUs); workgroup w
+// walks a contiguous range of element batches.  The loads of batch k+1 (gather indices
+// at the top of the iteration, then the x values and the pa_data z-columns right after
+// the z loop of batch k, into the registers batch k has just finished with) stay in
+// flight across the remaining barriers of batch k and the x/y contractions of batch k+1,
+// so HBM is being read during every phase except the z loop itself.  Issue order matters:
+// vmcnt retires in order, so the (small, needed-first) x gather is issued before the
+// pa_data stream.
+// ABL (tuning builds only, tools/ablate.hip): 0 = the kernel; 1 = memory traffic only (loads +
+// stores, no contractions); 2 = contractions only (pa_data not read).
+template <int KIND, int D, int Q, int NBZ, bool GATHER, bool ACCUM, bool BLK = false, int ABL = 0>
+__global__ void __launch_bounds__(Q*Q*NBZ, minw_for(KIND, D))
+k_pa_apply(const int64_t ne, const int64_t nbatches, const BasisT<D*Q> bg,
            const double *__restrict__ Dq, const double *__restrict__ x,
            const int *__restrict__ gmap, double *__restrict__ yE)
 {
@@ -51,212 +63,324 @@ k_pa_apply(const int64_t ne, const int64_t nblocks, const BasisT<D*Q> bg,
    constexpr int Q3 = Q*Q*Q;
    constexpr int SA = (D3 + NX*DDQ > NF*DQQ) ? D3 + NX*DDQ : NF*DQQ;
    constexpr int SV = NX*DDQ;
+   constexpr int NXV = (D3 + QQ - 1)/QQ;  // x values staged per thread
    __shared__ double smem[NBZ][SA + SV];
    __shared__ double sB[Q*D], sG[Q*D];
 
    const int a = threadIdx.x, b = threadIdx.y, tz = threadIdx.z;
-   const int64_t e = xcd_remap(blockIdx.x, nblocks)*NBZ + tz;
-   const bool active = e < ne;
-
-   // --- the HBM stream: this thread's z-column of pa_data, issued before any barrier
-   double O[Q][NC];
-   if (active)
-   {
-      const double *De = Dq + e*(int64_t)(NC*Q3) + b*Q + a;
-#pragma unroll
-      for (int qz = 0; qz < Q; qz++)
-      {
-#pragma unroll
-         for (int c = 0; c < NC; c++) { O[qz][c] = De[c*Q3 + qz*QQ]; }
-      }
-   }
-   else
-   {
-#pragma unroll
-      for (int qz = 0; qz < Q; qz++)
-      {
-#pragma unroll
-         for (int c = 0; c < NC; c++) { O[qz][c] = 0.0; }
-      }
-   }
+   const int t2 = a + Q*b;
+   // contiguous batch range of this workgroup; XCD-aware (workgroups w, w+8, ... share an L2)
+   const int64_t L = xcd_remap(blockIdx.x, gridDim.x);
+   const int64_t b0 = (L*nbatches)/gridDim.x, b1 = ((L + 1)*nbatches)/gridDim.x;
+   if (b0 >= b1) { return; }              // uniform over the workgroup, before any barrier
 
    double *sA = smem[tz];
    double *sX = sA, *sBX = sA + D3, *sGX = sBX + DDQ;   // phase 1 view of region A
    double *sT = sA;                                     // phase 2 view of region A
    double *sV = sA + SA;
 
-   const int t2 = a + Q*b;
-   for (int i = t2; i < D3; i += QQ)
-   {
-      double v = 0.0;
-      if (active)
-      {
-         if (GATHER)
-         {
-            const int g = gmap[e*D3 + i];
-            v = (g >= 0) ? x[g] : 0.0;
-         }
-         else { v = x[e*D3 + i]; }
-      }
-      sX[i] = v;
-   }
    for (int i = t2 + QQ*tz; i < Q*D; i += QQ*NBZ)
    {
       sB[i] = bg.b[i];
       if (KIND) { sG[i] = bg.g[i]; }
    }
-   __syncthreads();
 
-   // --- x contraction: thread (qx = a, dy = b)
-   if (b < D)
+   double O[Q][NC];
+   double xv[NXV];
+   int gi[NXV];
+
+   // ---- loaders (plain loads into registers; they survive the barriers) ----
+   // Every load is unconditional: out-of-range threads / elements read a clamped, valid
+   // address and their values are never stored.  Straight-line loads (no exec-mask
+   // branches) let the compiler place counted s_waitcnt vmcnt(N) instead of vmcnt(0), so
+   // the prefetched pa_data stays in flight while the gathered x values are consumed.
+   const int64_t elast = ne - 1;
+   auto load_gi = [&](const int64_t e)
    {
-      double Ba[D], Ga[D];
-#pragma unroll
-      for (int dx = 0; dx < D; dx++) { Ba[dx] = sB[a*D + dx]; Ga[dx] = KIND ? sG[a*D + dx] : 0.0; }
-#pragma unroll
-      for (int dz = 0; dz < D; dz++)
+      if (GATHER)
       {
-         double u = 0.0, v = 0.0;
+         const int *gm = gmap + (e < elast ? e : elast)*D3;
 #pragma unroll
-         for (int dx = 0; dx < D; dx++)
+         for (int k = 0; k < NXV; k++)
          {
-            const double s = sX[(dz*D + b)*D + dx];
-            u += Ba[dx]*s;
-            if (KIND) { v += Ga[dx]*s; }
+            const int i = t2 + k*QQ;
+            gi[k] = gm[i < D3 ? i : D3 - 1];
          }
-         sBX[(dz*D + b)*Q + a] = u;
-         if (KIND) { sGX[(dz*D + b)*Q + a] = v; }
       }
-   }
-   __syncthreads();
-
-   // --- y contraction into register z-columns: thread (qx = a, qy = b)
-   double r1[D], r2[D], r3[D];
+   };
+   auto load_xv = [&](const int64_t e)
    {
-      double Bb[D], Gb[D];
+      const double *xe = x + (e < elast ? e : elast)*D3;
 #pragma unroll
-      for (int dy = 0; dy < D; dy++) { Bb[dy] = sB[b*D + dy]; Gb[dy] = KIND ? sG[b*D + dy] : 0.0; }
-#pragma unroll
-      for (int dz = 0; dz < D; dz++)
+      for (int k = 0; k < NXV; k++)
       {
-         double u = 0.0, v = 0.0, w = 0.0;
-#pragma unroll
-         for (int dy = 0; dy < D; dy++)
+         const int i = t2 + k*QQ;
+         if (GATHER)
          {
-            const double bx = sBX[(dz*D + dy)*Q + a];
-            w += Bb[dy]*bx;
-            if (KIND)
+            const double v = x[gi[k] >= 0 ? gi[k] : 0];
+            xv[k] = gi[k] >= 0 ? v : 0.0;
+         }
+         else { xv[k] = xe[i < D3 ? i : D3 - 1]; }
+      }
+   };
+   auto load_O = [&](const int64_t e, const int64_t bt)
+   {
+      if (ABL == 2)
+      {
+#pragma unroll
+         for (int qz = 0; qz < Q; qz++)
+         {
+#pragma unroll
+            for (int c = 0; c < NC; c++) { O[qz][c] = xv[0] + (qz*NC + c); }
+         }
+         return;
+      }
+      if (BLK)
+      {
+         // blocked layout (common.h): whole-workgroup contiguous runs, 16 B per lane
+         if (KIND)
+         {
+            const double2 *Db = reinterpret_cast<const double2*>(Dq) + bt*(int64_t)(3*Q*NBZ*QQ) + tz*QQ + b*Q + a;
+#pragma unroll
+            for (int qz = 0; qz < Q; qz++)
             {
-               const double gx = sGX[(dz*D + dy)*Q + a];
-               u += Bb[dy]*gx;
-               v += Gb[dy]*bx;
+#pragma unroll
+               for (int cp = 0; cp < 3; cp++)
+               {
+                  const double2 v = Db[(qz*3 + cp)*(NBZ*QQ)];
+                  O[qz][(2*cp) % NC] = v.x; O[qz][(2*cp + 1) % NC] = v.y;
+               }
             }
          }
-         r1[dz] = u; r2[dz] = v; r3[dz] = w;
+         else
+         {
+            const double *Db = Dq + bt*(int64_t)(Q*NBZ*QQ) + tz*QQ + b*Q + a;
+#pragma unroll
+            for (int qz = 0; qz < Q; qz++) { O[qz][0] = Db[qz*(NBZ*QQ)]; }
+         }
+         return;
       }
+      const double *De = Dq + (e < elast ? e : elast)*(int64_t)(NC*Q3) + b*Q + a;
+#pragma unroll
+      for (int qz = 0; qz < Q; qz++)
+      {
+#pragma unroll
+         for (int c = 0; c < NC; c++) { O[qz][c] = De[c*Q3 + qz*QQ]; }
+      }
+   };
+
+   {
+      const int64_t e = b0*NBZ + tz;
+      load_gi(e);
+      load_xv(e);
+      load_O(e, b0);
    }
 
-   // --- z loop in registers: to the quadrature point, D matvec, back to dofs in z
-   double t1[D], t2r[D], t3[D];
-#pragma unroll
-   for (int dz = 0; dz < D; dz++) { t1[dz] = 0.0; t2r[dz] = 0.0; t3[dz] = 0.0; }
-#pragma unroll
-   for (int qz = 0; qz < Q; qz++)
+   for (int64_t bt = b0; bt < b1; bt++)
    {
-      if (KIND)
+      const int64_t e = bt*NBZ + tz;
+      const bool active = e < ne;
+      const int64_t btn = (bt + 1 < b1) ? bt + 1 : bt;  // last batch: harmless re-read of itself
+      const int64_t en = btn*NBZ + tz;
+      // opaque 0: keeps the per-thread basis rows (LDS reads below) from being hoisted out of
+      // the batch loop and held in ~90 VGPRs for the whole kernel
+      int vz;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+
+#pragma unroll
+      for (int k = 0; k < NXV; k++)
       {
-         double gX = 0.0, gY = 0.0, gZ = 0.0;
+         const int i = t2 + k*QQ;
+         if (i < D3) { sX[i] = xv[k]; }
+      }
+      load_gi(en);                        // next batch's gather indices: in flight from here
+      __syncthreads();
+      if (ABL == 1)
+      {
+         double acc = sX[t2 % D3];
+#pragma unroll
+         for (int qz = 0; qz < Q; qz++)
+         {
+#pragma unroll
+            for (int c = 0; c < NC; c++) { acc += O[qz][c]; }
+         }
+         __builtin_amdgcn_sched_barrier(0);
+         load_xv(en);
+         load_O(en, btn);
+         if (active)
+         {
+            for (int i = t2; i < D3; i += QQ) { yE[e*D3 + i] = acc; }
+         }
+         __syncthreads();
+         continue;
+      }
+
+      // --- x contraction: thread (qx = a, dy = b)
+      if (b < D)
+      {
+         double Ba[D], Ga[D];
+#pragma unroll
+         for (int dx = 0; dx < D; dx++) { Ba[dx] = sB[a*D + dx + vz]; Ga[dx] = KIND ? sG[a*D + dx + vz] : 0.0; }
 #pragma unroll
          for (int dz = 0; dz < D; dz++)
          {
-            const double bz = bg.b[qz*D + dz], gz = bg.g[qz*D + dz];
-            gX += bz*r1[dz];
-            gY += bz*r2[dz];
-            gZ += gz*r3[dz];
+            double u = 0.0, v = 0.0;
+#pragma unroll
+            for (int dx = 0; dx < D; dx++)
+            {
+               const double s = sX[(dz*D + b)*D + dx];
+               u += Ba[dx]*s;
+               if (KIND) { v += Ga[dx]*s; }
+            }
+            sBX[(dz*D + b)*Q + a] = u;
+            if (KIND) { sGX[(dz*D + b)*Q + a] = v; }
          }
-         const double O11 = O[qz][0], O12 = O[qz][1], O13 = O[qz][2];
-         const double O22 = O[qz][NC > 3 ? 3 : 0], O23 = O[qz][NC > 4 ? 4 : 0], O33 = O[qz][NC > 5 ? 5 : 0];
-         const double fX = (O11*gX) + (O12*gY) + (O13*gZ);
-         const double fY = (O12*gX) + (O22*gY) + (O23*gZ);
-         const double fZ = (O13*gX) + (O23*gY) + (O33*gZ);
+      }
+      __syncthreads();
+
+      // --- y contraction into register z-columns: thread (qx = a, qy = b)
+      double r1[D], r2[D], r3[D];
+      {
+         double Bb[D], Gb[D];
+#pragma unroll
+         for (int dy = 0; dy < D; dy++) { Bb[dy] = sB[b*D + dy + vz]; Gb[dy] = KIND ? sG[b*D + dy + vz] : 0.0; }
 #pragma unroll
          for (int dz = 0; dz < D; dz++)
          {
-            const double bz = bg.b[qz*D + dz], gz = bg.g[qz*D + dz];
-            t1[dz] += bz*fX;
-            t2r[dz] += bz*fY;
-            t3[dz] += gz*fZ;
+            double u = 0.0, v = 0.0, w = 0.0;
+#pragma unroll
+            for (int dy = 0; dy < D; dy++)
+            {
+               const double bx = sBX[(dz*D + dy)*Q + a];
+               w += Bb[dy]*bx;
+               if (KIND)
+               {
+                  const double gx = sGX[(dz*D + dy)*Q + a];
+                  u += Bb[dy]*gx;
+                  v += Gb[dy]*bx;
+               }
+            }
+            r1[dz] = u; r2[dz] = v; r3[dz] = w;
          }
       }
-      else
-      {
-         double u = 0.0;
-#pragma unroll
-         for (int dz = 0; dz < D; dz++) { u += bg.b[qz*D + dz]*r3[dz]; }
-         u *= O[qz][0];
-#pragma unroll
-         for (int dz = 0; dz < D; dz++) { t3[dz] += bg.b[qz*D + dz]*u; }
-      }
-   }
-   __syncthreads();   // all reads of sBX/sGX done; region A is reused as sT
-#pragma unroll
-   for (int dz = 0; dz < D; dz++)
-   {
-      sT[dz*QQ + b*Q + a] = t3[dz];
-      if (KIND)
-      {
-         sT[(D + dz)*QQ + b*Q + a] = t2r[dz];
-         sT[(2*D + dz)*QQ + b*Q + a] = t1[dz];
-      }
-   }
-   __syncthreads();
 
-   // --- transposed y contraction: thread (qx = a, dy = b)
-   if (b < D)
-   {
-      double Bc[Q], Gc[Q];
+      // --- z loop in registers: to the quadrature point, D matvec, back to dofs in z
+      // The wave-uniform basis factors are re-read from the kernel-argument segment every
+      // iteration (scalar loads, scalar cache): `zofs` is an opaque 0 that keeps the
+      // compiler from hoisting all 2*Q*D of them out of the batch loop, where they would
+      // not fit the SGPR file and spill to VGPR lanes.
+      int zofs;
+      asm volatile("s_mov_b32 %0, 0" : "=s"(zofs));
+      double t1[D], t2r[D], t3[D];
 #pragma unroll
-      for (int qy = 0; qy < Q; qy++) { Bc[qy] = sB[qy*D + b]; Gc[qy] = KIND ? sG[qy*D + b] : 0.0; }
+      for (int dz = 0; dz < D; dz++) { t1[dz] = 0.0; t2r[dz] = 0.0; t3[dz] = 0.0; }
 #pragma unroll
-      for (int dz = 0; dz < D; dz++)
+      for (int qz = 0; qz < Q; qz++)
       {
-         double v1 = 0.0, v23 = 0.0;
-#pragma unroll
-         for (int qy = 0; qy < Q; qy++)
+         if (KIND)
          {
-            v23 += Bc[qy]*sT[dz*QQ + qy*Q + a];
-            if (KIND)
+            double gX = 0.0, gY = 0.0, gZ = 0.0;
+#pragma unroll
+            for (int dz = 0; dz < D; dz++)
             {
-               v23 += Gc[qy]*sT[(D + dz)*QQ + qy*Q + a];
-               v1 += Bc[qy]*sT[(2*D + dz)*QQ + qy*Q + a];
+               const double bz = bg.b[qz*D + dz + zofs], gz = bg.g[qz*D + dz + zofs];
+               gX += bz*r1[dz];
+               gY += bz*r2[dz];
+               gZ += gz*r3[dz];
+            }
+            const double O11 = O[qz][0], O12 = O[qz][1], O13 = O[qz][2];
+            const double O22 = O[qz][NC > 3 ? 3 : 0], O23 = O[qz][NC > 4 ? 4 : 0], O33 = O[qz][NC > 5 ? 5 : 0];
+            const double fX = (O11*gX) + (O12*gY) + (O13*gZ);
+            const double fY = (O12*gX) + (O22*gY) + (O23*gZ);
+            const double fZ = (O13*gX) + (O23*gY) + (O33*gZ);
+#pragma unroll
+            for (int dz = 0; dz < D; dz++)
+            {
+               const double bz = bg.b[qz*D + dz + zofs], gz = bg.g[qz*D + dz + zofs];
+               t1[dz] += bz*fX;
+               t2r[dz] += bz*fY;
+               t3[dz] += gz*fZ;
             }
          }
-         sV[(dz*D + b)*Q + a] = v23;
-         if (KIND) { sV[DDQ + (dz*D + b)*Q + a] = v1; }
-      }
-   }
-   __syncthreads();
-
-   // --- transposed x contraction and store: thread (dx = a, dy = b)
-   if (a < D && b < D && active)
-   {
-      double Bc[Q], Gc[Q];
+         else
+         {
+            double u = 0.0;
 #pragma unroll
-      for (int qx = 0; qx < Q; qx++) { Bc[qx] = sB[qx*D + a]; Gc[qx] = KIND ? sG[qx*D + a] : 0.0; }
-      double *ye = yE + e*D3 + b*D + a;
+            for (int dz = 0; dz < D; dz++) { u += bg.b[qz*D + dz + zofs]*r3[dz]; }
+            u *= O[qz][0];
+#pragma unroll
+            for (int dz = 0; dz < D; dz++) { t3[dz] += bg.b[qz*D + dz + zofs]*u; }
+         }
+      }
+      __syncthreads();   // all reads of sBX/sGX done; region A is reused as sT
 #pragma unroll
       for (int dz = 0; dz < D; dz++)
       {
-         double y = 0.0;
-#pragma unroll
-         for (int qx = 0; qx < Q; qx++)
+         sT[dz*QQ + b*Q + a] = t3[dz];
+         if (KIND)
          {
-            y += Bc[qx]*sV[(dz*D + b)*Q + qx];
-            if (KIND) { y += Gc[qx]*sV[DDQ + (dz*D + b)*Q + qx]; }
+            sT[(D + dz)*QQ + b*Q + a] = t2r[dz];
+            sT[(2*D + dz)*QQ + b*Q + a] = t1[dz];
          }
-         if (ACCUM) { ye[dz*D*D] += y; }
-         else { ye[dz*D*D] = y; }
       }
+      // --- next batch: x values first (needed first; vmcnt retires in order), then pa_data.
+      // The scheduling fence keeps these loads below the z loop: hoisted above it they would
+      // need a second set of 2*NC*Q registers and cost a wave of occupancy.
+      __builtin_amdgcn_sched_barrier(0);
+      load_xv(en);
+      load_O(en, btn);
+      __syncthreads();
+
+      // --- transposed y contraction: thread (qx = a, dy = b)
+      if (b < D)
+      {
+         double Bc[Q], Gc[Q];
+#pragma unroll
+         for (int qy = 0; qy < Q; qy++) { Bc[qy] = sB[qy*D + b + vz]; Gc[qy] = KIND ? sG[qy*D + b + vz] : 0.0; }
+#pragma unroll
+         for (int dz = 0; dz < D; dz++)
+         {
+            double v1 = 0.0, v23 = 0.0;
+#pragma unroll
+            for (int qy = 0; qy < Q; qy++)
+            {
+               v23 += Bc[qy]*sT[dz*QQ + qy*Q + a];
+               if (KIND)
+               {
+                  v23 += Gc[qy]*sT[(D + dz)*QQ + qy*Q + a];
+                  v1 += Bc[qy]*sT[(2*D + dz)*QQ + qy*Q + a];
+               }
+            }
+            sV[(dz*D + b)*Q + a] = v23;
+            if (KIND) { sV[DDQ + (dz*D + b)*Q + a] = v1; }
+         }
+      }
+      __syncthreads();
+
+      // --- transposed x contraction and store: thread (dx = a, dy = b)
+      if (a < D && b < D && active)
+      {
+         double Bc[Q], Gc[Q];
+#pragma unroll
+         for (int qx = 0; qx < Q; qx++) { Bc[qx] = sB[qx*D + a + vz]; Gc[qx] = KIND ? sG[qx*D + a + vz] : 0.0; }
+         double *ye = yE + e*D3 + b*D + a;
+#pragma unroll
+         for (int dz = 0; dz < D; dz++)
+         {
+            double y = 0.0;
+#pragma unroll
+            for (int qx = 0; qx < Q; qx++)
+            {
+               y += Bc[qx]*sV[(dz*D + b)*Q + qx];
+               if (KIND) { y += Gc[qx]*sV[DDQ + (dz*D + b)*Q + qx]; }
+            }
+            if (ACCUM) { ye[dz*D*D] += y; }
+            else { ye[dz*D*D] = y; }
+         }
+      }
+      // no barrier needed here: the next iteration writes sX (region A), whose last readers
+      // (the transposed y contraction) are behind the barrier above; sV is next written
+      // three barriers from now.
    }
 }
 
@@ -422,27 +546,42 @@ static void fill_basis(BasisT<N> &bg, int D, int Q, const double *B, const doubl
 typedef int (*apply_fn)(int64_t ne, const double *B, const double *G, const double *Dq,
                         const double *x, const int *gmap, double *yE, hipStream_t s);
 
-template <int KIND, int D, int Q, bool GATHER, bool ACCUM>
+template <int KIND, int D, int Q, bool GATHER, bool ACCUM, bool BLK>
 static int launch_apply(int64_t ne, const double *B, const double *G, const double *Dq,
                         const double *x, const int *gmap, double *yE, hipStream_t s)
 {
    constexpr int NBZ = nbz_for(Q);
+   auto kern = k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM, BLK>;
+   // resident workgroups on the current device (queried once per instantiation and device)
+   static int resident[64] = {0};
+   int dev = 0;
+   if (int rc = check_hip(hipGetDevice(&dev), "hipGetDevice")) { return rc; }
+   if (dev < 0 || dev >= 64) { dev = 0; }
+   if (resident[dev] == 0)
+   {
+      int per_cu = 0, cus = 0;
+      if (int rc = check_hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, Q*Q*NBZ, 0),
+                             "hipOccupancyMaxActiveBlocksPerMultiprocessor")) { return rc; }
+      if (int rc = check_hip(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev),
+                             "hipDeviceGetAttribute")) { return rc; }
+      if (per_cu < 1) { per_cu = 1; }
+      resident[dev] = per_cu*cus;
+   }
    BasisT<D*Q> bg;
    fill_basis(bg, D, Q, B, G);
    const int64_t nb = (ne + NBZ - 1)/NBZ;
    if (nb == 0) { return 0; }
-   MFA_REQUIRE(nb < (int64_t)2147483647, "pa_apply: too many workgroups (%lld)", (long long)nb);
-   k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM><<<dim3((unsigned)nb), dim3(Q, Q, NBZ), 0, s>>>(
-      ne, nb, bg, Dq, x, gmap, yE);
+   const unsigned grid = (unsigned)(nb < resident[dev] ? nb : resident[dev]);
+   kern<<<dim3(grid), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, bg, Dq, x, gmap, yE);
    MFA_CHECK_LAUNCH("k_pa_apply");
    return 0;
 }
 
-template <int KIND, bool GATHER, bool ACCUM>
+template <int KIND, bool GATHER, bool ACCUM, bool BLK>
 static apply_fn find_apply(int D, int Q)
 {
 #define MFA_CASE(DD, QQ) \
-   if (D == DD && Q == QQ) { return launch_apply<KIND, DD, QQ, GATHER, ACCUM>; }
+   if (D == DD && Q == QQ) { return launch_apply<KIND, DD, QQ, GATHER, ACCUM, BLK>; }
    MFA_CASE(2, 2) MFA_CASE(2, 3) MFA_CASE(3, 3) MFA_CASE(3, 4) MFA_CASE(4, 4) MFA_CASE(4, 5)
    MFA_CASE(5, 5) MFA_CASE(5, 6) MFA_CASE(6, 6) MFA_CASE(6, 7) MFA_CASE(7, 7) MFA_CASE(7, 8)
    MFA_CASE(8, 8) MFA_CASE(8, 9) MFA_CASE(9, 9) MFA_CASE(9, 10)
@@ -450,7 +589,7 @@ static apply_fn find_apply(int D, int Q)
    return nullptr;
 }
 
-template <int KIND, bool GATHER, bool ACCUM>
+template <int KIND, bool GATHER, bool ACCUM, bool BLK>
 static int run_apply(int D, int Q, int64_t ne, const double *B, const double *G,
                      const double *Dq, const double *x, const int *gmap, double *yE,
                      hipStream_t s)
@@ -459,7 +598,8 @@ static int run_apply(int D, int Q, int64_t ne, const double *B, const double *G,
                "pa_apply: unsupported (D1D,Q1D) = (%d,%d); limits D1D<=%d, Q1D<=%d, D1D*Q1D<=%d",
                D, Q, MAX_D1D, MAX_Q1D, MAX_DQ);
    MFA_REQUIRE(B && Dq && x && yE && (KIND == 0 || G) && (!GATHER || gmap), "pa_apply: null pointer argument");
-   if (apply_fn f = find_apply<KIND, GATHER, ACCUM>(D, Q)) { return f(ne, B, G, Dq, x, gmap, yE, s); }
+   if (apply_fn f = find_apply<KIND, GATHER, ACCUM, BLK>(D, Q)) { return f(ne, B, G, Dq, x, gmap, yE, s); }
+   MFA_REQUIRE(!BLK, "pa_apply: the blocked pa_data layout needs a specialised (D1D,Q1D); (%d,%d) is not registered", D, Q);
    report_fallback(KIND ? "PADiffusionApply3D" : "PAMassApply3D", D, Q);
    if (ne == 0) { return 0; }
    MFA_REQUIRE(ne < (int64_t)2147483647, "pa_apply: too many elements for the fallback kernel");
@@ -479,11 +619,16 @@ static int run_apply(int D, int Q, int64_t ne, const double *B, const double *G,
    return 0;
 }
 
-int pa_apply_L2E(int kind, int D, int Q, int64_t ne, const double *B, const double *G,
+int pa_apply_L2E(int kind, int layout, int D, int Q, int64_t ne, const double *B, const double *G,
                  const double *Dq, const int *gmap, const double *x, double *yE, hipStream_t s)
 {
-   if (kind == 0) { return run_apply<0, true, false>(D, Q, ne, B, G, Dq, x, gmap, yE, s); }
-   return run_apply<1, true, false>(D, Q, ne, B, G, Dq, x, gmap, yE, s);
+   if (layout)
+   {
+      if (kind == 0) { return run_apply<0, true, false, true>(D, Q, ne, B, G, Dq, x, gmap, yE, s); }
+      return run_apply<1, true, false, true>(D, Q, ne, B, G, Dq, x, gmap, yE, s);
+   }
+   if (kind == 0) { return run_apply<0, true, false, false>(D, Q, ne, B, G, Dq, x, gmap, yE, s); }
+   return run_apply<1, true, false, false>(D, Q, ne, B, G, Dq, x, gmap, yE, s);
 }
 
 } // namespace mfa
@@ -492,8 +637,8 @@ using namespace mfa;
 
 extern "C" int mfem_amd_has_specialization(int kind, int D1D, int Q1D)
 {
-   if (kind == 0) { return find_apply<0, false, true>(D1D, Q1D) != nullptr; }
-   return find_apply<1, false, true>(D1D, Q1D) != nullptr;
+   if (kind == 0) { return find_apply<0, false, true, false>(D1D, Q1D) != nullptr; }
+   return find_apply<1, false, true, false>(D1D, Q1D) != nullptr;
 }
 
 extern "C" int mfem_amd_pa_diffusion_apply_3d(int D1D, int Q1D, int64_t ne, int symmetric,
@@ -502,20 +647,28 @@ extern "C" int mfem_amd_pa_diffusion_apply_3d(int D1D, int Q1D, int64_t ne, int 
                                               void *stream)
 {
    MFA_REQUIRE(symmetric, "pa_diffusion_apply_3d: only the symmetric (6-component) D is supported");
-   return run_apply<1, false, true>(D1D, Q1D, ne, B, G, D, xE, nullptr, yE, as_stream(stream));
+   return run_apply<1, false, true, false>(D1D, Q1D, ne, B, G, D, xE, nullptr, yE, as_stream(stream));
 }
 
 extern "C" int mfem_amd_pa_mass_apply_3d(int D1D, int Q1D, int64_t ne, const double *B,
                                          const double *D, const double *xE, double *yE,
                                          void *stream)
 {
-   return run_apply<0, false, true>(D1D, Q1D, ne, B, nullptr, D, xE, nullptr, yE, as_stream(stream));
+   return run_apply<0, false, true, false>(D1D, Q1D, ne, B, nullptr, D, xE, nullptr, yE, as_stream(stream));
 }
 
-extern "C" int mfem_amd_pa_apply_L2E(int kind, int D1D, int Q1D, int64_t ne, const double *B,
-                                     const double *G, const double *D, const int *gather_map,
-                                     const double *x, double *yE, void *stream)
+extern "C" int mfem_amd_pa_apply_L2E(int kind, int pa_layout, int D1D, int Q1D, int64_t ne,
+                                     const double *B, const double *G, const double *D,
+                                     const int *gather_map, const double *x, double *yE,
+                                     void *stream)
 {
    MFA_REQUIRE(kind == 0 || kind == 1, "pa_apply_L2E: kind must be 0 (mass) or 1 (diffusion)");
-   return pa_apply_L2E(kind, D1D, Q1D, ne, B, G, D, gather_map, x, yE, as_stream(stream));
+   MFA_REQUIRE(pa_layout == 0 || pa_layout == 1, "pa_apply_L2E: pa_layout must be 0 (MFEM) or 1 (blocked)");
+   return pa_apply_L2E(kind, pa_layout, D1D, Q1D, ne, B, G, D, gather_map, x, yE, as_stream(stream));
+}
+
+extern "C" int64_t mfem_amd_pa_data_size(int kind, int pa_layout, int Q1D, int64_t ne)
+{
+   if (pa_layout) { return blocked_size(kind, Q1D, ne); }
+   return ne*(int64_t)(kind ? 6 : 1)*Q1D*Q1D*Q1D;
 }

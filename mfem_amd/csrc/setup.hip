@@ -137,7 +137,8 @@ __global__ void __launch_bounds__(256)
 k_setup_from_nodes(const int kind, const int Dn, const int Q, const int coeffDim,
                    const BasisT<MAX_DQ> bg, const double *__restrict__ W,
                    const double *__restrict__ nodesE, const double *__restrict__ C,
-                   const int const_c, double *__restrict__ D, double *__restrict__ detJ_out)
+                   const int const_c, double *__restrict__ D, double *__restrict__ detJ_out,
+                   const int layout)
 {
    extern __shared__ __align__(16) double dyn[];
    const int64_t e = blockIdx.x;
@@ -155,15 +156,28 @@ k_setup_from_nodes(const int kind, const int Dn, const int Q, const int coeffDim
       {
          const double C1 = c[0], C2 = c[coeffDim == 3 ? 1 : 0], C3 = c[coeffDim == 3 ? 2 : 0];
          diffusion_point(J11, J21, J31, J12, J22, J32, J13, J23, J33, W[q], C1, C2, C3, out, detJ);
-         for (int k = 0; k < 6; k++) { D[q + (int64_t)Q3*(k + 6*e)] = out[k]; }
+         for (int k = 0; k < 6; k++) { D[layout ? blocked_index(1, Q, e, q, k) : q + (int64_t)Q3*(k + 6*e)] = out[k]; }
       }
       else
       {
          detJ = J11*(J22*J33 - J32*J23) - J21*(J12*J33 - J32*J13) + J31*(J12*J23 - J22*J13);
-         D[q + (int64_t)Q3*e] = W[q]*c[0]*detJ;
+         D[layout ? blocked_index(0, Q, e, q, 0) : q + (int64_t)Q3*e] = W[q]*c[0]*detJ;
       }
       if (detJ_out) { detJ_out[q + (int64_t)Q3*e] = detJ; }
    }
+}
+
+// MFEM layout (q, c, e) -> blocked layout (common.h); padding entries are left untouched.
+__global__ void __launch_bounds__(256)
+k_to_blocked(const int kind, const int Q, const int64_t n, const double *__restrict__ Din,
+             double *__restrict__ Dout)
+{
+   const int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x;
+   if (i >= n) { return; }
+   const int Q3 = Q*Q*Q, nc = kind ? 6 : 1;
+   const int q = (int)(i % Q3), c = (int)((i/Q3) % nc);
+   const int64_t e = i/((int64_t)Q3*nc);
+   Dout[blocked_index(kind, Q, e, q, c)] = Din[i];
 }
 
 __global__ void __launch_bounds__(256)
@@ -363,11 +377,12 @@ extern "C" int mfem_amd_mass_setup_3d(int Q1D, int64_t ne, const double *W, cons
 extern "C" int mfem_amd_pa_setup_from_nodes_3d(int kind, int Dn, int Q1D, int coeffDim,
                                                int64_t ne, const double *Bn, const double *Gn,
                                                const double *W, const double *nodesE,
-                                               const double *C, int const_c, double *D,
-                                               double *detJ_out, void *stream)
+                                               const double *C, int const_c, int pa_layout,
+                                               double *D, double *detJ_out, void *stream)
 {
    if (ne == 0) { return 0; }
    MFA_REQUIRE(kind == 0 || kind == 1, "pa_setup_from_nodes_3d: kind must be 0 or 1");
+   MFA_REQUIRE(pa_layout == 0 || pa_layout == 1, "pa_setup_from_nodes_3d: pa_layout must be 0 or 1");
    MFA_REQUIRE(coeffDim == 1 || (kind == 1 && coeffDim == 3), "pa_setup_from_nodes_3d: coeffDim = %d unsupported", coeffDim);
    MFA_REQUIRE(ne > 0 && ne < 2147483647 && W && nodesE && C && D && Gn, "pa_setup_from_nodes_3d: bad arguments");
    BasisT<MAX_DQ> bg;
@@ -376,8 +391,20 @@ extern "C" int mfem_amd_pa_setup_from_nodes_3d(int kind, int Dn, int Q1D, int co
    const size_t lds = jac_lds_bytes(Dn, Q1D);
    if (int rc = set_lds(k_setup_from_nodes, lds)) { return rc; }
    k_setup_from_nodes<<<dim3((unsigned)ne), dim3(256), lds, as_stream(stream)>>>(
-      kind, Dn, Q1D, coeffDim, bg, dW, nodesE, C, const_c, D, detJ_out);
+      kind, Dn, Q1D, coeffDim, bg, dW, nodesE, C, const_c, D, detJ_out, pa_layout);
    MFA_CHECK_LAUNCH("k_setup_from_nodes");
+   return 0;
+}
+
+extern "C" int mfem_amd_pa_data_to_blocked(int kind, int Q1D, int64_t ne, const double *D,
+                                           double *Dblocked, void *stream)
+{
+   if (ne == 0) { return 0; }
+   MFA_REQUIRE((kind == 0 || kind == 1) && Q1D >= 1 && Q1D <= MAX_Q1D && D && Dblocked && D != Dblocked,
+               "pa_data_to_blocked: bad arguments");
+   const int64_t n = ne*(int64_t)(kind ? 6 : 1)*Q1D*Q1D*Q1D;
+   k_to_blocked<<<dim3((unsigned)((n + 255)/256)), dim3(256), 0, as_stream(stream)>>>(kind, Q1D, n, D, Dblocked);
+   MFA_CHECK_LAUNCH("k_to_blocked");
    return 0;
 }
 

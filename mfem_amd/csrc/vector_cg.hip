@@ -21,7 +21,7 @@ namespace mfa
 
 constexpr int RED_BLOCKS_MAX = 1024;       // partials per reduction
 
-int pa_apply_L2E(int kind, int D, int Q, int64_t ne, const double *B, const double *G,
+int pa_apply_L2E(int kind, int layout, int D, int Q, int64_t ne, const double *B, const double *G,
                  const double *Dq, const int *gmap, const double *x, double *yE, hipStream_t s);
 int scatter_dot(int64_t ndofs, const int *offsets, const int *indices, const double *xE,
                 double *y, const unsigned char *marker, const double *xin, const double *w,
@@ -310,7 +310,7 @@ static int constrained_mult(const mfem_amd_pa_operator *op, const double *x, dou
    MFA_REQUIRE(op->yE && op->offsets && op->indices && op->pa_data, "pa operator: null array");
    // NOTE: the element kernel is not gated by `skip`: after convergence it only rewrites
    // the work E-vector, and the gated transpose-gather leaves y untouched.
-   if (int rc = pa_apply_L2E(op->kind, op->D1D, op->Q1D, op->ne, op->B, op->G, op->pa_data, gm, x, op->yE, s)) { return rc; }
+   if (int rc = pa_apply_L2E(op->kind, op->pa_layout, op->D1D, op->Q1D, op->ne, op->B, op->G, op->pa_data, gm, x, op->yE, s)) { return rc; }
    return scatter_dot(op->ndofs, op->offsets, op->indices, op->yE, y, ess ? op->ess_marker : nullptr,
                       x, w, partials, nb, skip, s);
 }

@@ -34,11 +34,17 @@ def hB(a):
 class DeviceOperator:
     """mfem_amd_pa_operator filled from a golden case (or any dict with the same keys)."""
 
-    def __init__(self, c, ess=None):
+    def __init__(self, c, ess=None, layout=0):
         self.c = c
+        self.layout = layout
         D1, NE = c["D1D"], c["NE"]
         self.B, self.G = hB(c["B"]), hB(c["G"])
         self.pa = dev(c["pa_data"])
+        if layout:
+            nb = capi.lib.mfem_amd_pa_data_size(c["kind"], 1, c["Q1D"], NE)
+            blk = zeros(nb)
+            capi.call("mfem_amd_pa_data_to_blocked", c["kind"], c["Q1D"], NE, ptr(self.pa), ptr(blk), None)
+            self.pa = blk
         self.gm = dev(c["gather_map"], np.int32)
         self.off = dev(c["offsets"], np.int32)
         self.ind = dev(c["indices"], np.int32)
@@ -52,7 +58,7 @@ class DeviceOperator:
             self.masked = zeros(NE*D1**3, torch.int32)
             capi.call("mfem_amd_mask_gather_map", NE*D1**3, ptr(self.gm), ptr(self.marker), ptr(self.masked), None)
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
-        self.op = capi.PaOperator(c["kind"], D1, c["Q1D"], NE, c["ndofs"], vp(self.B), vp(self.G),
+        self.op = capi.PaOperator(c["kind"], layout, D1, c["Q1D"], NE, c["ndofs"], vp(self.B), vp(self.G),
                                   ptr(self.pa), ptr(self.gm), ptr(self.masked), ptr(self.off), ptr(self.ind),
                                   len(ess), ptr(self.ess), ptr(self.marker), ptr(self.yE))
 
@@ -60,7 +66,7 @@ class DeviceOperator:
         """unconstrained y = A x: fused gather+apply, then transpose-gather"""
         c = self.c
         y = zeros(c["ndofs"])
-        capi.call("mfem_amd_pa_apply_L2E", c["kind"], c["D1D"], c["Q1D"], c["NE"], self.B, self.G, ptr(self.pa),
+        capi.call("mfem_amd_pa_apply_L2E", c["kind"], self.layout, c["D1D"], c["Q1D"], c["NE"], self.B, self.G, ptr(self.pa),
                   ptr(self.gm), ptr(x), ptr(self.yE), None)
         capi.call("mfem_amd_restrict_scatter", c["ndofs"], ptr(self.off), ptr(self.ind), ptr(self.yE), ptr(y), 0, 0, None)
         return y

@@ -77,9 +77,18 @@ def test_geometry_and_setup(gh, name):
         capi.call("mfem_amd_mass_setup_3d", Q, NE, gh.ptr(W), gh.ptr(detJ), gh.ptr(coeff), const_c, gh.ptr(D1), None)
     assert relerr(gh.host(D1), c["pa_data"]) < TOL
     capi.call("mfem_amd_pa_setup_from_nodes_3d", c["kind"], Dn, Q, 1, NE, gh.hB(c["nodes_B"]), gh.hB(c["nodes_G"]),
-              gh.ptr(W), gh.ptr(nE), gh.ptr(coeff), const_c, gh.ptr(D2), gh.ptr(det2), None)
+              gh.ptr(W), gh.ptr(nE), gh.ptr(coeff), const_c, 0, gh.ptr(D2), gh.ptr(det2), None)
     assert relerr(gh.host(D2), c["pa_data"]) < TOL
     assert relerr(gh.host(det2), c["detJ"]) < TOL
+    # blocked (HBM) layout: a pure permutation of the same values -> bit-identical to converting D2
+    nblk = capi.lib.mfem_amd_pa_data_size(c["kind"], 1, Q, NE)
+    assert nblk >= ncomp*Q**3*NE and capi.lib.mfem_amd_pa_data_size(c["kind"], 0, Q, NE) == ncomp*Q**3*NE
+    D3, D4 = gh.zeros(nblk), gh.zeros(nblk)
+    capi.call("mfem_amd_pa_setup_from_nodes_3d", c["kind"], Dn, Q, 1, NE, gh.hB(c["nodes_B"]), gh.hB(c["nodes_G"]),
+              gh.ptr(W), gh.ptr(nE), gh.ptr(coeff), const_c, 1, gh.ptr(D3), None, None)
+    capi.call("mfem_amd_pa_data_to_blocked", c["kind"], Q, NE, gh.ptr(D2), gh.ptr(D4), None)
+    assert np.array_equal(gh.host(D3), gh.host(D4))
+    assert np.array_equal(np.sort(gh.host(D4)[gh.host(D4) != 0]), np.sort(gh.host(D2)[gh.host(D2) != 0]))
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -108,6 +117,10 @@ def test_apply_and_diag(gh, name):
     oop = orc.Operator(c["kind"], D1, Q1, NE, c["ndofs"], c["B"], c["G"], c["pa_data"], c["gather_map"],
                        c["offsets"], c["indices"])
     assert relerr(y, oop.mult(c["x"])) < TOL                           # vs the CPU oracle
+    if capi.lib.mfem_amd_has_specialization(c["kind"], D1, Q1):
+        # blocked pa_data layout: same arithmetic on permuted storage -> bit-identical
+        opb = gh.DeviceOperator(c, layout=1)
+        assert np.array_equal(gh.host(opb.apply_L2L(gh.dev(c["x"]))), y)
     # element and L diagonals
     dE = gh.zeros(NE*nd)
     if c["kind"]:
@@ -122,8 +135,10 @@ def test_apply_and_diag(gh, name):
 def test_constrained_operator_and_pcg(gh, name):
     from mfem_amd import capi
     c = load_case(name)
+    from mfem_amd import capi as _capi
     n, ess = c["ndofs"], c["ess_tdof"]
-    op = gh.DeviceOperator(c, ess)
+    layout = int(_capi.lib.mfem_amd_has_specialization(c["kind"], c["D1D"], c["Q1D"]) and c["NE"] % 2 == 0)
+    op = gh.DeviceOperator(c, ess, layout=layout)     # alternate layouts over the cases
     y = gh.host(op.constrained_mult(gh.dev(c["x"])))
     assert relerr(y, c["y_constrained"]) < TOL
     assert np.array_equal(y[ess], c["x"][ess])
