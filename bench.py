@@ -203,9 +203,9 @@ def main():
         dE = torch.zeros(ne*D**3, dtype=torch.float64, device=dev)
         diag, dinv = torch.empty_like(x), torch.empty_like(x)
         if kind:
-            capi.call("mfem_amd_pa_diffusion_diag_3d", D, Q, ne, 1, B, G, ptr(pa), ptr(dE), stream)
+            capi.call("mfem_amd_pa_diffusion_diag_3d", D, Q, ne, 1, B, G, ptr(pa), LAYOUT, ptr(dE), stream)
         else:
-            capi.call("mfem_amd_pa_mass_diag_3d", D, Q, ne, B, ptr(pa), ptr(dE), stream)
+            capi.call("mfem_amd_pa_mass_diag_3d", D, Q, ne, B, ptr(pa), LAYOUT, ptr(dE), stream)
         capi.call("mfem_amd_restrict_scatter", ndofs, ptr(off), ptr(ind), ptr(dE), ptr(diag), 0, 1, stream)
         capi.call("mfem_amd_jacobi_setup", ndofs, ptr(diag), 1.0, len(ess), ptr(essd), ptr(dinv), stream)
         del dE

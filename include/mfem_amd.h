@@ -130,9 +130,9 @@ int mfem_amd_pa_mass_apply_3d(int D1D, int Q1D, int64_t ne, const double *B,
  * DiagonalKernelType fem/bilininteg.hpp:2187-2189).  diagE += diag(A_e). */
 int mfem_amd_pa_diffusion_diag_3d(int D1D, int Q1D, int64_t ne, int symmetric,
                                   const double *B, const double *G, const double *D,
-                                  double *diagE, void *stream);
+                                  int pa_layout, double *diagE, void *stream);
 int mfem_amd_pa_mass_diag_3d(int D1D, int Q1D, int64_t ne, const double *B,
-                             const double *D, double *diagE, void *stream);
+                             const double *D, int pa_layout, double *diagE, void *stream);
 
 /* PABilinearFormExtension::MultInternal, H1 branch, one integrator
  * (fem/bilinearform_ext.cpp:487-564): yE = A_E (gather x) with the L->E gather fused into

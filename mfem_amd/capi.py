@@ -49,8 +49,8 @@ _SIGS = {
     "mfem_amd_pa_data_to_blocked": (cint, [cint, cint, i64, vp, vp, vp]),
     "mfem_amd_pa_diffusion_apply_3d": (cint, [cint, cint, i64, cint, _hd, _hd, vp, vp, vp, vp]),
     "mfem_amd_pa_mass_apply_3d": (cint, [cint, cint, i64, _hd, vp, vp, vp, vp]),
-    "mfem_amd_pa_diffusion_diag_3d": (cint, [cint, cint, i64, cint, _hd, _hd, vp, vp, vp]),
-    "mfem_amd_pa_mass_diag_3d": (cint, [cint, cint, i64, _hd, vp, vp, vp]),
+    "mfem_amd_pa_diffusion_diag_3d": (cint, [cint, cint, i64, cint, _hd, _hd, vp, cint, vp, vp]),
+    "mfem_amd_pa_mass_diag_3d": (cint, [cint, cint, i64, _hd, vp, cint, vp, vp]),
     "mfem_amd_pa_apply_L2E": (cint, [cint, cint, cint, cint, i64, _hd, _hd, vp, vp, vp, vp, vp]),
     "mfem_amd_set_marker": (cint, [i64, vp, vp, vp]),
     "mfem_amd_mask_gather_map": (cint, [i64, vp, vp, vp, vp]),

@@ -26,6 +26,7 @@
 //  * Logical block ids are remapped so every XCD (private L2) works on one contiguous
 //    element range.
 #include "common.h"
+#include <cstdlib>
 
 namespace mfa
 {
@@ -50,9 +51,9 @@ constexpr int minw_for(int KIND, int D)
 // pa_data stream.
 // ABL (tuning builds only, tools/ablate.hip): 0 = the kernel; 1 = memory traffic only (loads +
 // stores, no contractions); 2 = contractions only (pa_data not read).
-template <int KIND, int D, int Q, int NBZ, bool GATHER, bool ACCUM, bool BLK = false, int ABL = 0>
+template <int KIND, int D, int Q, int NBZ, bool GATHER, bool ACCUM, bool BLK = false, int ABL = 0, bool PERSIST = true>
 __global__ void __launch_bounds__(Q*Q*NBZ, minw_for(KIND, D))
-k_pa_apply(const int64_t ne, const int64_t nbatches, const BasisT<D*Q> bg,
+k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const BasisT<D*Q> bg,
            const double *__restrict__ Dq, const double *__restrict__ x,
            const int *__restrict__ gmap, double *__restrict__ yE)
 {
@@ -70,8 +71,16 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const BasisT<D*Q> bg,
    const int a = threadIdx.x, b = threadIdx.y, tz = threadIdx.z;
    const int t2 = a + Q*b;
    // contiguous batch range of this workgroup; XCD-aware (workgroups w, w+8, ... share an L2)
-   const int64_t L = xcd_remap(blockIdx.x, gridDim.x);
-   const int64_t b0 = (L*nbatches)/gridDim.x, b1 = ((L + 1)*nbatches)/gridDim.x;
+   // batch schedule: SCHED 0 = contiguous range per workgroup (XCD-aware); 1 = round-robin
+   // (workgroup w takes batches w, w+G, ...: at any time the grid works on G consecutive
+   // batches, so the chip reads/writes one moving window of memory, like a streaming copy)
+   // PERSIST = false: one batch per workgroup (grid = nbatches), nothing prefetched.
+   const int SCHED = PERSIST ? sched : 1;
+   const int64_t G_ = gridDim.x;
+   const int64_t L = SCHED ? (int64_t)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+   const int64_t b0 = SCHED ? L : (L*nbatches)/G_;
+   const int64_t b1 = SCHED ? nbatches : ((L + 1)*nbatches)/G_;
+   const int64_t bstep = SCHED ? G_ : 1;
    if (b0 >= b1) { return; }              // uniform over the workgroup, before any barrier
 
    double *sA = smem[tz];
@@ -97,6 +106,12 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const BasisT<D*Q> bg,
    const int64_t elast = ne - 1;
    auto load_gi = [&](const int64_t e)
    {
+      if (ABL & 8)
+      {
+#pragma unroll
+         for (int k = 0; k < NXV; k++) { gi[k] = 0; }
+         return;
+      }
       if (GATHER)
       {
          const int *gm = gmap + (e < elast ? e : elast)*D3;
@@ -110,6 +125,12 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const BasisT<D*Q> bg,
    };
    auto load_xv = [&](const int64_t e)
    {
+      if (ABL & 8)
+      {
+#pragma unroll
+         for (int k = 0; k < NXV; k++) { xv[k] = 1.0; }
+         return;
+      }
       const double *xe = x + (e < elast ? e : elast)*D3;
 #pragma unroll
       for (int k = 0; k < NXV; k++)
@@ -176,11 +197,11 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const BasisT<D*Q> bg,
       load_O(e, b0);
    }
 
-   for (int64_t bt = b0; bt < b1; bt++)
+   for (int64_t bt = b0; bt < b1; bt += bstep)
    {
       const int64_t e = bt*NBZ + tz;
       const bool active = e < ne;
-      const int64_t btn = (bt + 1 < b1) ? bt + 1 : bt;  // last batch: harmless re-read of itself
+      const int64_t btn = (bt + bstep < b1) ? bt + bstep : bt;  // last batch: harmless re-read of itself
       const int64_t en = btn*NBZ + tz;
       // opaque 0: keeps the per-thread basis rows (LDS reads below) from being hoisted out of
       // the batch loop and held in ~90 VGPRs for the whole kernel
@@ -193,9 +214,9 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const BasisT<D*Q> bg,
          const int i = t2 + k*QQ;
          if (i < D3) { sX[i] = xv[k]; }
       }
-      load_gi(en);                        // next batch's gather indices: in flight from here
+      if (PERSIST) { load_gi(en); }       // next batch's gather indices: in flight from here
       __syncthreads();
-      if (ABL == 1)
+      if (ABL & 1)
       {
          double acc = sX[t2 % D3];
 #pragma unroll
@@ -207,10 +228,26 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const BasisT<D*Q> bg,
          __builtin_amdgcn_sched_barrier(0);
          load_xv(en);
          load_O(en, btn);
-         if (active)
+         if (ABL & 16)
+         {
+            const int tid = t2 + QQ*tz;
+            const int nst = (ABL & 128) ? 64 : QQ*NBZ;   // 128: only wave 0 stores
+            if (tid < nst)
+            for (int i = tid; i < NBZ*D3; i += nst)
+            {
+               if (bt*NBZ*D3 + i < ne*D3)
+               {
+                  if (ABL & 32) { __builtin_nontemporal_store(acc, &yE[bt*NBZ*D3 + i]); }
+                  else if (ABL & 64) { yE[(blockIdx.x*NBZ*D3 + i) % (ne*D3)] = acc; }
+                  else { yE[bt*NBZ*D3 + i] = acc; }
+               }
+            }
+         }
+         else if (active && !(ABL & 4))
          {
             for (int i = t2; i < D3; i += QQ) { yE[e*D3 + i] = acc; }
          }
+         if ((ABL & 4) && acc == 1.2345e-300) { yE[0] = acc; }
          __syncthreads();
          continue;
       }
@@ -327,8 +364,11 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const BasisT<D*Q> bg,
       // The scheduling fence keeps these loads below the z loop: hoisted above it they would
       // need a second set of 2*NC*Q registers and cost a wave of occupancy.
       __builtin_amdgcn_sched_barrier(0);
-      load_xv(en);
-      load_O(en, btn);
+      if (PERSIST)
+      {
+         load_xv(en);
+         load_O(en, btn);
+      }
       __syncthreads();
 
       // --- transposed y contraction: thread (qx = a, dy = b)
@@ -543,6 +583,22 @@ static void fill_basis(BasisT<N> &bg, int D, int Q, const double *B, const doubl
    }
 }
 
+// Schedule of the element kernel per (operator, order); tuned on MI355X (profiles/r1).
+// MFEM_AMD_APPLY_MODE=0|1|2 overrides it (tuning aid).
+static int apply_mode(int KIND, int D, int Q)
+{
+   static int forced = -2;
+   if (forced == -2)
+   {
+      const char *v = getenv("MFEM_AMD_APPLY_MODE");
+      forced = (v && *v >= '0' && *v <= '2') ? (*v - '0') : -1;
+   }
+   if (forced >= 0) { return forced; }
+   // measured (profiles/r1/sweep_modes.txt): one batch per workgroup wins up to p = 7 (BP3);
+   // the persistent round-robin schedule wins where registers allow one wave per SIMD only
+   return (KIND == 1 && (D >= 9 || (D == 8 && Q == 8))) ? 2 : 0;
+}
+
 typedef int (*apply_fn)(int64_t ne, const double *B, const double *G, const double *Dq,
                         const double *x, const int *gmap, double *yE, hipStream_t s);
 
@@ -551,7 +607,9 @@ static int launch_apply(int64_t ne, const double *B, const double *G, const doub
                         const double *x, const int *gmap, double *yE, hipStream_t s)
 {
    constexpr int NBZ = nbz_for(Q);
-   auto kern = k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM, BLK>;
+   const int mode = apply_mode(KIND, D, Q);   // 0 one batch per workgroup, 1 persistent/contiguous, 2 persistent/round-robin
+   auto kern = k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM, BLK, 0, true>;
+   auto kern1 = k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM, BLK, 0, false>;
    // resident workgroups on the current device (queried once per instantiation and device)
    static int resident[64] = {0};
    int dev = 0;
@@ -571,8 +629,16 @@ static int launch_apply(int64_t ne, const double *B, const double *G, const doub
    fill_basis(bg, D, Q, B, G);
    const int64_t nb = (ne + NBZ - 1)/NBZ;
    if (nb == 0) { return 0; }
-   const unsigned grid = (unsigned)(nb < resident[dev] ? nb : resident[dev]);
-   kern<<<dim3(grid), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, bg, Dq, x, gmap, yE);
+   if (mode == 0)
+   {
+      MFA_REQUIRE(nb < (int64_t)2147483647, "pa_apply: too many workgroups (%lld)", (long long)nb);
+      kern1<<<dim3((unsigned)nb), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, 1, bg, Dq, x, gmap, yE);
+   }
+   else
+   {
+      const unsigned grid = (unsigned)(nb < resident[dev] ? nb : resident[dev]);
+      kern<<<dim3(grid), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, mode == 2 ? 1 : 0, bg, Dq, x, gmap, yE);
+   }
    MFA_CHECK_LAUNCH("k_pa_apply");
    return 0;
 }

@@ -58,12 +58,44 @@ k_scatter(const int64_t ndofs, const int *__restrict__ offsets,
    for (int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x; i < ndofs; i += (int64_t)gridDim.x*256)
    {
       const int o0 = offsets[i], o1 = offsets[i + 1];
+      const int n = o1 - o0;
       double v = 0.0;
-      for (int j = o0; j < o1; j++)
+      // The sum is sequential and left-to-right from 0 (the reference's order), but the
+      // loads are independent: fetch all indices, then all values, then add in order.
+      // Hex meshes have multiplicity 1 (interior), 2 (face), 4 (edge), 8 (vertex) on
+      // conforming interior dofs; anything longer takes the plain loop.
+      if (n <= 2)
       {
-         const int idx = indices[j];
-         const double t = xE[idx >= 0 ? idx : -1 - idx];
-         v += (idx >= 0 || MODE == 2) ? t : -t;
+         if (n > 0)
+         {
+            const int i0 = indices[o0], i1 = indices[o1 - 1];
+            const double t0 = xE[i0 >= 0 ? i0 : -1 - i0], t1 = xE[i1 >= 0 ? i1 : -1 - i1];
+            v += (i0 >= 0 || MODE == 2) ? t0 : -t0;
+            if (n == 2) { v += (i1 >= 0 || MODE == 2) ? t1 : -t1; }
+         }
+      }
+      else if (n <= 8)
+      {
+         int id[8];
+         double t[8];
+#pragma unroll
+         for (int k = 0; k < 8; k++) { id[k] = indices[o0 + (k < n ? k : n - 1)]; }
+#pragma unroll
+         for (int k = 0; k < 8; k++) { t[k] = xE[id[k] >= 0 ? id[k] : -1 - id[k]]; }
+#pragma unroll
+         for (int k = 0; k < 8; k++)
+         {
+            if (k < n) { v += (id[k] >= 0 || MODE == 2) ? t[k] : -t[k]; }
+         }
+      }
+      else
+      {
+         for (int j = o0; j < o1; j++)
+         {
+            const int idx = indices[j];
+            const double t = xE[idx >= 0 ? idx : -1 - idx];
+            v += (idx >= 0 || MODE == 2) ? t : -t;
+         }
       }
       if (marker && marker[i]) { v = xin[i]; }
       if (MODE == 1) { v += y[i]; }

@@ -228,7 +228,7 @@ k_mass_setup(const int64_t n, const int Q3, const double *__restrict__ W,
 template <int KIND>
 __global__ void __launch_bounds__(256)
 k_diag(const int D, const int Q, const BasisT<MAX_DQ> bg, const double *__restrict__ Dq,
-       double *__restrict__ Y)
+       double *__restrict__ Y, const int layout)
 {
    extern __shared__ __align__(16) double dyn[];
    const int Q3 = Q*Q*Q, QQ = Q*Q, D3 = D*D*D;
@@ -242,14 +242,15 @@ k_diag(const int D, const int Q, const BasisT<MAX_DQ> bg, const double *__restri
    {
       const int ii = pass/3, jj = pass % 3;
       const int k = KIND ? (jj >= ii ? 3 - (3 - ii)*(2 - ii)/2 + jj : 3 - (3 - jj)*(2 - jj)/2 + ii) : 0;
-      const double *De = Dq + (int64_t)Q3*(k + (KIND ? 6 : 1)*e);
+      const double *De = Dq + (int64_t)Q3*(k + (KIND ? 6 : 1)*e);   // layout 0
       for (int i = tid; i < QQ*D; i += nt)        // [qx][qy][dz]
       {
          const int dz = i % D, qy = (i/D) % Q, qx = i/(D*Q);
          double s = 0.0;
          for (int qz = 0; qz < Q; qz++)
          {
-            const double O = De[qx + Q*(qy + Q*qz)];
+            const int q = qx + Q*(qy + Q*qz);
+            const double O = layout ? Dq[blocked_index(KIND, Q, e, q, k)] : De[q];
             const double Bz = sB[qz*D + dz], Gz = sG[qz*D + dz];
             const double L = (KIND && ii == 2) ? Gz : Bz, R = (KIND && jj == 2) ? Gz : Bz;
             s += L*O*R;
@@ -410,30 +411,33 @@ extern "C" int mfem_amd_pa_data_to_blocked(int kind, int Q1D, int64_t ne, const 
 
 extern "C" int mfem_amd_pa_diffusion_diag_3d(int D1D, int Q1D, int64_t ne, int symmetric,
                                              const double *B, const double *G, const double *D,
-                                             double *diagE, void *stream)
+                                             int pa_layout, double *diagE, void *stream)
 {
    if (ne == 0) { return 0; }
+   MFA_REQUIRE(pa_layout == 0 || pa_layout == 1, "pa_diffusion_diag_3d: pa_layout must be 0 or 1");
    MFA_REQUIRE(symmetric, "pa_diffusion_diag_3d: only the symmetric (6-component) D is supported");
    MFA_REQUIRE(ne > 0 && ne < 2147483647 && D && diagE && G, "pa_diffusion_diag_3d: bad arguments");
    BasisT<MAX_DQ> bg;
    if (int rc = fill_basis_dyn(bg, D1D, Q1D, B, G)) { return rc; }
    const size_t lds = sizeof(double)*(size_t)(2*Q1D*D1D + Q1D*Q1D*D1D + Q1D*D1D*D1D);
    if (int rc = set_lds(k_diag<1>, lds)) { return rc; }
-   k_diag<1><<<dim3((unsigned)ne), dim3(256), lds, as_stream(stream)>>>(D1D, Q1D, bg, D, diagE);
+   k_diag<1><<<dim3((unsigned)ne), dim3(256), lds, as_stream(stream)>>>(D1D, Q1D, bg, D, diagE, pa_layout);
    MFA_CHECK_LAUNCH("k_diag<diffusion>");
    return 0;
 }
 
 extern "C" int mfem_amd_pa_mass_diag_3d(int D1D, int Q1D, int64_t ne, const double *B,
-                                        const double *D, double *diagE, void *stream)
+                                        const double *D, int pa_layout, double *diagE,
+                                        void *stream)
 {
    if (ne == 0) { return 0; }
+   MFA_REQUIRE(pa_layout == 0 || pa_layout == 1, "pa_mass_diag_3d: pa_layout must be 0 or 1");
    MFA_REQUIRE(ne > 0 && ne < 2147483647 && D && diagE, "pa_mass_diag_3d: bad arguments");
    BasisT<MAX_DQ> bg;
    if (int rc = fill_basis_dyn(bg, D1D, Q1D, B, nullptr)) { return rc; }
    const size_t lds = sizeof(double)*(size_t)(2*Q1D*D1D + Q1D*Q1D*D1D + Q1D*D1D*D1D);
    if (int rc = set_lds(k_diag<0>, lds)) { return rc; }
-   k_diag<0><<<dim3((unsigned)ne), dim3(256), lds, as_stream(stream)>>>(D1D, Q1D, bg, D, diagE);
+   k_diag<0><<<dim3((unsigned)ne), dim3(256), lds, as_stream(stream)>>>(D1D, Q1D, bg, D, diagE, pa_layout);
    MFA_CHECK_LAUNCH("k_diag<mass>");
    return 0;
 }

@@ -19,7 +19,7 @@
 namespace mfa
 {
 
-constexpr int RED_BLOCKS_MAX = 1024;       // partials per reduction
+constexpr int RED_BLOCKS_MAX = 8192;       // partials per reduction
 
 int pa_apply_L2E(int kind, int layout, int D, int Q, int64_t ne, const double *B, const double *G,
                  const double *Dq, const int *gmap, const double *x, double *yE, hipStream_t s);
@@ -29,7 +29,7 @@ int scatter_dot(int64_t ndofs, const int *offsets, const int *indices, const dou
 
 static inline int red_blocks(int64_t n)
 {
-   int64_t nb = (n + 256*8 - 1)/(256*8);     // >= 8 elements per thread before adding blocks
+   int64_t nb = (n + 256*4 - 1)/(256*4);     // >= 4 elements per thread before adding blocks
    if (nb < 1) { nb = 1; }
    if (nb > RED_BLOCKS_MAX) { nb = RED_BLOCKS_MAX; }
    return (int)nb;
@@ -65,7 +65,7 @@ k_dot_partial(const int64_t n, const double *__restrict__ x, const double *__res
    if (threadIdx.x == 0) { partials[blockIdx.x] = r; }
 }
 
-// Sum of nb (<= 1024) partials by one workgroup, fixed order: thread t adds partials
+// Sum of nb (<= RED_BLOCKS_MAX) partials by one workgroup, fixed order: thread t adds partials
 // t, t+256, ... then the fixed block tree.
 __device__ __forceinline__ double final_sum(const double *partials, const int nb, double *s4)
 {

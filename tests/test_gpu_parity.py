@@ -122,12 +122,17 @@ def test_apply_and_diag(gh, name):
         opb = gh.DeviceOperator(c, layout=1)
         assert np.array_equal(gh.host(opb.apply_L2L(gh.dev(c["x"]))), y)
     # element and L diagonals
-    dE = gh.zeros(NE*nd)
-    if c["kind"]:
-        capi.call("mfem_amd_pa_diffusion_diag_3d", D1, Q1, NE, 1, B, G, gh.ptr(pa), gh.ptr(dE), None)
-    else:
-        capi.call("mfem_amd_pa_mass_diag_3d", D1, Q1, NE, B, gh.ptr(pa), gh.ptr(dE), None)
-    assert relerr(gh.host(dE), c["diagE"]) < TOL
+    for lay in (0, 1):
+        dE = gh.zeros(NE*nd)
+        pad = pa
+        if lay:
+            pad = gh.zeros(capi.lib.mfem_amd_pa_data_size(c["kind"], 1, Q1, NE))
+            capi.call("mfem_amd_pa_data_to_blocked", c["kind"], Q1, NE, gh.ptr(pa), gh.ptr(pad), None)
+        if c["kind"]:
+            capi.call("mfem_amd_pa_diffusion_diag_3d", D1, Q1, NE, 1, B, G, gh.ptr(pad), lay, gh.ptr(dE), None)
+        else:
+            capi.call("mfem_amd_pa_mass_diag_3d", D1, Q1, NE, B, gh.ptr(pad), lay, gh.ptr(dE), None)
+        assert relerr(gh.host(dE), c["diagE"]) < TOL
     assert capi.lib.mfem_amd_has_specialization(c["kind"], D1, Q1) == int(Q1 in (D1, D1 + 1) and 2 <= D1 <= 9)
 
 

@@ -26,7 +26,7 @@ for p in [int(a) for a in sys.argv[1].split(",")]:
     yE = torch.empty(ne*D**3, dtype=torch.float64, device=dev)
     b1, _ = bench.algorithmic_bytes(1, D, Q, ne, ndofs)
     for gpc in [int(a) for a in sys.argv[2].split(",")]:
-        for abl, blk in ((0, 0), (0, 1), (1, 0), (1, 1), (2, 0)):
+        for abl, blk in ((0, 1), (256, 1), (17, 1), (273, 1), (5, 1)):
             def f():
                 rc = lib.ablate_run(D, abl, blk, ne, B, G, pa.data_ptr(), x.data_ptr(), gm.data_ptr(), yE.data_ptr(), gpc)
                 assert rc == 0, rc
@@ -36,4 +36,4 @@ for p in [int(a) for a in sys.argv[1].split(",")]:
             for _ in range(10): f()
             e1.record(); torch.cuda.synchronize()
             tt = e0.elapsed_time(e1)*1e-3/10
-            print(f"p={p} grid/CU={gpc} blk={blk} abl={abl} ({['full','mem-only','compute-only'][abl]}): {tt*1e6:8.1f} us  {b1/tt/1e9:7.1f} GB/s", flush=True)
+            print(f"p={p} grid/CU={gpc} blk={blk} abl={abl} ({ {0:'full',1:'mem-only',2:'compute-only',5:'mem-only no-store',17:'mem-only coalesced-store',273:'mem-only coalesced-store, contiguous ranges',256:'full, contiguous ranges',145:'mem-only wave0-only store',49:'mem-only coalesced nt-store',81:'mem-only store to small L2-resident region',9:'mem-only no-gather',13:'mem-only no-store no-gather'}[abl]}): {tt*1e6:8.1f} us  {b1/tt/1e9:7.1f} GB/s", flush=True)
