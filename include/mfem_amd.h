@@ -197,7 +197,7 @@ typedef struct mfem_amd_pa_operator
    const int *offsets, *indices;
    int64_t ness;
    const int *ess;           /* constraint_list */
-   const unsigned char *ess_marker; /* ndofs bytes */
+   const unsigned char *ess_marker; /* ndofs bytes: 1 essential, 2 essential ghost copy (multi-GPU) */
    double *yE;               /* work: NE*D1D^3 doubles */
 } mfem_amd_pa_operator;
 
@@ -235,6 +235,52 @@ int mfem_amd_pcg_pa(const mfem_amd_pa_operator *op, const double *dinv, const do
                     double *x, double rel_tol, double abs_tol, int max_iter,
                     int check_every, void *workspace, mfem_amd_pcg_result *result,
                     double *hist, void *stream);
+
+/* ---- multi-GPU: shared-dof exchange + global reductions --------------------------- */
+
+/* DeviceConformingProlongationOperator's device kernels (fem/pfespace.cpp):
+ * ExtractSubVector (:5347) buf[i] = x[idx[i]]; SetSubVector (:5371) y[idx[i]] = buf[i];
+ * AddSubVector (:5475-5494) y[unq_ldof[i]] += sum_{j in [unq_shr_i[i], unq_shr_i[i+1])}
+ * shr_buf[unq_shr_j[j]], in that fixed order (deterministic). */
+int mfem_amd_shared_pack(int64_t n, const int *idx, const double *x, double *buf, void *stream);
+int mfem_amd_shared_unpack(int64_t n, const int *idx, const double *buf, double *y, void *stream);
+int mfem_amd_shared_accumulate(int64_t nuniq, const int *unq_ldof, const int *unq_shr_i,
+                               const int *unq_shr_j, const double *shr_buf, double *y,
+                               void *stream);
+
+/* Communicator seen by the solver: three callbacks, all asynchronous on `stream` (a
+ * hipStream_t).  The reference's counterpart is GroupCommunicator + MPI_Allreduce
+ * (general/communication.cpp:724-1042, linalg/vector.hpp:773-779); here the transport is
+ * RCCL over xGMI (torch.distributed, backend "nccl", in the Python host; see
+ * mfem_amd/parallel.py) or anything else that honours the contract.  Vectors live on the
+ * local L-dofs with non-owned (ghost) entries kept at 0 between operator applications.
+ *   forward(v): P    -- ghost entries of v := the owner's value (pfespace.cpp:5401-5447)
+ *   reverse(v): P^T  -- owner entries += ghost entries of the sharing ranks, in fixed
+ *                       neighbour order; then the local ghost entries := 0 (:5503-5539)
+ *   allreduce_sum(buf, n): in-place sum over ranks of n device doubles.
+ * Return 0 on success. */
+typedef struct mfem_amd_comm
+{
+   void *ctx;
+   int (*allreduce_sum)(void *ctx, double *dev_buf, int n, void *stream);
+   int (*forward)(void *ctx, double *v, void *stream);
+   int (*reverse)(void *ctx, double *v, void *stream);
+} mfem_amd_comm;
+
+/* RAPOperator(P, ConstrainedOperator(A), P)::Mult (linalg/operator.cpp:433,586-646):
+ * forward(x) [ghosts of x are overwritten], y = A x on local dofs, reverse(y).
+ * op->ess_marker: 1 = essential & owned (y = x), 2 = essential ghost copy (y = 0). */
+int mfem_amd_pa_par_mult(const mfem_amd_pa_operator *op, const mfem_amd_comm *comm, double *x,
+                         double *y, void *stream);
+/* CGSolver(MPI_Comm)::Mult (linalg/solvers.cpp:44-54,869-1050) on the partitioned
+ * operator: mfem_amd_pcg_pa with every dot product all-reduced (one double each, the
+ * reference's message shape) and the operator wrapped in the exchange.  b must hold 0 in
+ * ghost entries; x is returned consistent on owners and ghosts.  All ranks take identical
+ * decisions (they see the same reduced scalars). */
+int mfem_amd_pcg_pa_par(const mfem_amd_pa_operator *op, const mfem_amd_comm *comm,
+                        const double *dinv, const double *b, double *x, double rel_tol,
+                        double abs_tol, int max_iter, int check_every, void *workspace,
+                        mfem_amd_pcg_result *result, double *hist, void *stream);
 
 #ifdef __cplusplus
 }

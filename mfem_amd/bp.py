@@ -1,0 +1,144 @@
+"""CEED bake-off problem driver on the C ABI (device-resident), the Python twin of
+tests/benchmarks/bench_ceed.cpp `BakeOff`/`Problem`/`Kernel`: Cartesian hex mesh, H1 order
+p, BP1 (mass) / BP3 (diffusion, GL) / BP5 (diffusion, GLL), all-boundary Dirichlet,
+Jacobi-PCG.  Serial, or one box per rank with the exchange of mfem_amd/parallel.py.
+torch supplies device memory and the stream; every computation is a HIP kernel of
+libmfem_amd.so."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+from .cartesian import CartesianProblem
+from .tables import bakeoff_tables
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class BakeoffProblem:
+    def __init__(self, problem, p, n, device, part=None, exchange=None, layout=1):
+        self.dev = torch.device(device)
+        self.part, self.ex, self.layout = part, exchange, layout
+        self.prob = part.prob if part is not None else CartesianProblem(p, n[0], n[1], n[2])
+        pr = self.prob
+        self.kind, self.D, self.Q, self.B, self.G, Bn, Gn, W = bakeoff_tables(problem, p)
+        kind, D, Q = self.kind, self.D, self.Q
+        self.ne, self.ndofs = pr.ne, pr.ndofs
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+        self.stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        self.gm, self.off, self.ind = t(pr.gather_map), t(pr.offsets), t(pr.indices)
+        nodesE, Wd, one = t(pr.nodes_E), t(W), torch.ones(1, dtype=torch.float64, device=self.dev)
+        self.pa = torch.zeros(capi.lib.mfem_amd_pa_data_size(kind, layout, Q, self.ne), dtype=torch.float64, device=self.dev)
+        capi.call("mfem_amd_pa_setup_from_nodes_3d", kind, 2, Q, 1, self.ne, Bn, Gn, _p(Wd), _p(nodesE), _p(one), 1,
+                  layout, _p(self.pa), None, self.stream)
+        self.yE = torch.empty(self.ne*D**3, dtype=torch.float64, device=self.dev)
+        # essential dofs: all six faces of the global box (bench_ceed.cpp:99-100)
+        if part is not None:
+            marker, ess = part.essential_marker()
+        else:
+            ess = pr.boundary_dofs()
+            marker = np.zeros(self.ndofs, np.uint8); marker[ess] = 1
+        self.ess_host = ess
+        self.ess, self.marker = t(ess.astype(np.int32)), t(marker)
+        self.masked = torch.empty(self.ne*D**3, dtype=torch.int32, device=self.dev)
+        capi.call("mfem_amd_mask_gather_map", self.ne*D**3, _p(self.gm), _p(self.marker), _p(self.masked), self.stream)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        self.op = capi.PaOperator(kind, layout, D, Q, self.ne, self.ndofs, vp(self.B), vp(self.G), _p(self.pa),
+                                  _p(self.gm), _p(self.masked), _p(self.off), _p(self.ind), len(ess), _p(self.ess),
+                                  _p(self.marker), _p(self.yE))
+        self.ghost = t(part.ext_ldof) if part is not None else None
+        self._dinv = None
+        self._ws = None
+        self._comm = None
+
+    # ---- BilinearForm::Mult (unconstrained L->L), the BK "Kernel" of bench_ceed.cpp:163-190
+    def l2e(self, x):
+        capi.call("mfem_amd_pa_apply_L2E", self.kind, self.layout, self.D, self.Q, self.ne, self.B, self.G, _p(self.pa),
+                  _p(self.gm), _p(x), _p(self.yE), self.stream)
+
+    def e2l(self, y):
+        capi.call("mfem_amd_restrict_scatter", self.ndofs, _p(self.off), _p(self.ind), _p(self.yE), _p(y), 0, 0, self.stream)
+
+    def mult(self, x, y):
+        """y = A x; in parallel x's ghost entries are refreshed first and y ends with owners
+        summed / ghosts zero (P^T A P)."""
+        if self.ex is not None:
+            self.ex.forward(x.data_ptr(), self.stream)
+        self.l2e(x)
+        self.e2l(y)
+        if self.ex is not None:
+            self.ex.reverse(y.data_ptr(), self.stream)
+
+    # ---- OperatorJacobiSmoother(a, ess) (linalg/solvers.cpp:331-348,401-425)
+    def dinv(self):
+        if self._dinv is None:
+            dE = torch.zeros(self.ne*self.D**3, dtype=torch.float64, device=self.dev)
+            diag = torch.empty(self.ndofs, dtype=torch.float64, device=self.dev)
+            if self.kind:
+                capi.call("mfem_amd_pa_diffusion_diag_3d", self.D, self.Q, self.ne, 1, self.B, self.G, _p(self.pa),
+                          self.layout, _p(dE), self.stream)
+            else:
+                capi.call("mfem_amd_pa_mass_diag_3d", self.D, self.Q, self.ne, self.B, _p(self.pa), self.layout, _p(dE),
+                          self.stream)
+            capi.call("mfem_amd_restrict_scatter", self.ndofs, _p(self.off), _p(self.ind), _p(dE), _p(diag), 0, 1, self.stream)
+            if self.ex is not None:                 # ParBilinearForm::AssembleDiagonal: one P^T exchange
+                self.ex.reverse(diag.data_ptr(), self.stream)
+                if self.ghost.numel():              # keep 1/0 out of the ghost entries
+                    capi.call("mfem_amd_set_subvector", self.ghost.numel(), _p(self.ghost), None, 1.0, _p(diag), self.stream)
+            self.diag = diag
+            dinv = torch.empty_like(diag)
+            capi.call("mfem_amd_jacobi_setup", self.ndofs, _p(diag), 1.0, self.ess.numel(), _p(self.ess), _p(dinv), self.stream)
+            if self.ex is not None and self.ghost.numel():
+                capi.call("mfem_amd_set_subvector", self.ghost.numel(), _p(self.ghost), None, 0.0, _p(dinv), self.stream)
+            self._dinv = dinv
+        return self._dinv
+
+    def rhs_unit_source(self):
+        """b_i = (1, phi_i) with essential rows eliminated (x_ess = 0): b = M 1 since the basis
+        is a partition of unity.  In parallel: owners summed, ghosts zero."""
+        # mass data on THIS problem's rule (so BP5 uses its GLL rule)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+        from .tables import gauss_legendre, gauss_lobatto, lagrange_tables
+        Qm = self.Q
+        qx, qw = (gauss_lobatto(Qm) if Qm == self.D else gauss_legendre(Qm))
+        Bm, Gm = self.B, self.G
+        Bn, Gn = lagrange_tables(np.array([0.0, 1.0]), qx)
+        W = np.ascontiguousarray((qw[None, None, :]*qw[None, :, None]*qw[:, None, None]).reshape(-1))
+        pam = torch.zeros(capi.lib.mfem_amd_pa_data_size(0, 0, Qm, self.ne), dtype=torch.float64, device=self.dev)
+        one = torch.ones(1, dtype=torch.float64, device=self.dev)
+        Wd, nodesE = t(W), t(self.prob.nodes_E)      # keep the device tensors alive across the launch
+        capi.call("mfem_amd_pa_setup_from_nodes_3d", 0, 2, Qm, 1, self.ne, Bn, Gn, _p(Wd), _p(nodesE), _p(one),
+                  1, 0, _p(pam), None, self.stream)
+        ones = torch.ones(self.ndofs, dtype=torch.float64, device=self.dev)
+        b = torch.empty_like(ones)
+        capi.call("mfem_amd_pa_apply_L2E", 0, 0, self.D, Qm, self.ne, Bm, Gm, _p(pam), _p(self.gm), _p(ones), _p(self.yE), self.stream)
+        self.e2l(b)
+        if self.ex is not None:
+            self.ex.reverse(b.data_ptr(), self.stream)
+        capi.call("mfem_amd_set_subvector", self.ess.numel(), _p(self.ess), None, 0.0, _p(b), self.stream)
+        torch.cuda.current_stream(self.dev).synchronize()   # temporaries above die here
+        return b
+
+    # ---- CGSolver / PCG
+    def pcg(self, b, rel_tol, abs_tol=0.0, max_iter=2000, check_every=8, jacobi=True, want_hist=False):
+        nbytes = capi.lib.mfem_amd_pcg_workspace_bytes(self.ndofs, max_iter)
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+            self._comm = self.ex.make_comm(self._ws) if self.ex is not None else None
+        x = torch.empty(self.ndofs, dtype=torch.float64, device=self.dev)
+        res = capi.PcgResult()
+        hist = np.zeros(max_iter + 2) if want_hist else None
+        hp = hist.ctypes.data_as(C.c_void_p) if want_hist else None
+        dinv = self.dinv() if jacobi else None
+        if self.ex is None:
+            capi.call("mfem_amd_pcg_pa", C.byref(self.op), _p(dinv), _p(b), _p(x), rel_tol, abs_tol, max_iter, check_every,
+                      _p(self._ws), C.byref(res), hp, self.stream)
+        else:
+            rc = capi.lib.mfem_amd_pcg_pa_par(C.byref(self.op), C.byref(self._comm), _p(dinv), _p(b), _p(x), rel_tol, abs_tol,
+                                              max_iter, check_every, _p(self._ws), C.byref(res), hp, self.stream)
+            if rc != 0:
+                raise capi.MfemAmdError(f"{capi.lib.mfem_amd_last_error().decode()} / {self.ex.error!r}")
+        return x, res, (hist[:res.iterations + 1] if want_hist else None)

@@ -27,6 +27,15 @@ class PaOperator(C.Structure):
                 ("ness", i64), ("ess", vp), ("ess_marker", vp), ("yE", vp)]
 
 
+AR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+EX_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+
+
+class Comm(C.Structure):
+    """struct mfem_amd_comm"""
+    _fields_ = [("ctx", vp), ("allreduce_sum", AR_FN), ("forward", EX_FN), ("reverse", EX_FN)]
+
+
 class PcgResult(C.Structure):
     """struct mfem_amd_pcg_result"""
     _fields_ = [("iterations", cint), ("converged", cint), ("initial_nom", dbl), ("final_nom", dbl)]
@@ -63,6 +72,12 @@ _SIGS = {
     "mfem_amd_jacobi_apply": (cint, [i64, vp, vp, vp, vp]),
     "mfem_amd_pa_constrained_mult": (cint, [C.POINTER(PaOperator), vp, vp, vp]),
     "mfem_amd_pcg_workspace_bytes": (i64, [i64, cint]),
+    "mfem_amd_shared_pack": (cint, [i64, vp, vp, vp, vp]),
+    "mfem_amd_shared_unpack": (cint, [i64, vp, vp, vp, vp]),
+    "mfem_amd_shared_accumulate": (cint, [i64, vp, vp, vp, vp, vp, vp]),
+    "mfem_amd_pa_par_mult": (cint, [C.POINTER(PaOperator), C.POINTER(Comm), vp, vp, vp]),
+    "mfem_amd_pcg_pa_par": (cint, [C.POINTER(PaOperator), C.POINTER(Comm), vp, vp, vp, dbl, dbl, cint, cint, vp,
+                                   C.POINTER(PcgResult), vp, vp]),
     "mfem_amd_pcg_pa": (cint, [C.POINTER(PaOperator), vp, vp, vp, dbl, dbl, cint, cint, vp,
                                C.POINTER(PcgResult), vp, vp]),
 }

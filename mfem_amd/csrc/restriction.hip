@@ -97,7 +97,11 @@ k_scatter(const int64_t ndofs, const int *__restrict__ offsets,
             v += (idx >= 0 || MODE == 2) ? t : -t;
          }
       }
-      if (marker && marker[i]) { v = xin[i]; }
+      if (marker)
+      {
+         const unsigned char m = marker[i];           // 1: essential (owned) -> x; 2: essential ghost -> 0
+         if (m) { v = (m == 1) ? xin[i] : 0.0; }
+      }
       if (MODE == 1) { v += y[i]; }
       y[i] = v;
       if (DOT) { prod += w[i]*v; }
@@ -134,6 +138,34 @@ k_set_subvector(const int64_t n, const int *__restrict__ list, const double *__r
    if (i >= n) { return; }
    const int k = list[i];
    y[k] = x ? x[k] : value;
+}
+
+// Shared-dof exchange kernels (DeviceConformingProlongationOperator, fem/pfespace.cpp:5347-5494)
+__global__ void __launch_bounds__(256)
+k_pack(const int64_t n, const int *__restrict__ idx, const double *__restrict__ x, double *__restrict__ buf)
+{
+   const int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x;
+   if (i < n) { buf[i] = x[idx[i]]; }
+}
+
+__global__ void __launch_bounds__(256)
+k_unpack(const int64_t n, const int *__restrict__ idx, const double *__restrict__ buf, double *__restrict__ y)
+{
+   const int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x;
+   if (i < n) { y[idx[i]] = buf[i]; }
+}
+
+__global__ void __launch_bounds__(256)
+k_accumulate(const int64_t n, const int *__restrict__ dst, const int *__restrict__ off,
+             const int *__restrict__ src, const double *__restrict__ buf, double *__restrict__ y)
+{
+   const int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x;
+   if (i >= n) { return; }
+   const int k = dst[i];
+   double sum = y[k];
+   const int end = off[i + 1];
+   for (int j = off[i]; j != end; ++j) { sum += buf[src[j]]; }
+   y[k] = sum;
 }
 
 static inline unsigned grid_for(int64_t n) { return (unsigned)((n + 255)/256); }
@@ -240,5 +272,34 @@ extern "C" int mfem_amd_set_subvector(int64_t nlist, const int *list, const doub
    MFA_REQUIRE(nlist > 0 && list && y, "set_subvector: bad arguments");
    k_set_subvector<<<dim3(grid_for(nlist)), dim3(256), 0, as_stream(stream)>>>(nlist, list, x, value, y);
    MFA_CHECK_LAUNCH("k_set_subvector");
+   return 0;
+}
+
+extern "C" int mfem_amd_shared_pack(int64_t n, const int *idx, const double *x, double *buf, void *stream)
+{
+   if (n == 0) { return 0; }
+   MFA_REQUIRE(n > 0 && idx && x && buf, "shared_pack: bad arguments");
+   k_pack<<<dim3(grid_for(n)), dim3(256), 0, as_stream(stream)>>>(n, idx, x, buf);
+   MFA_CHECK_LAUNCH("k_pack");
+   return 0;
+}
+
+extern "C" int mfem_amd_shared_unpack(int64_t n, const int *idx, const double *buf, double *y, void *stream)
+{
+   if (n == 0) { return 0; }
+   MFA_REQUIRE(n > 0 && idx && buf && y, "shared_unpack: bad arguments");
+   k_unpack<<<dim3(grid_for(n)), dim3(256), 0, as_stream(stream)>>>(n, idx, buf, y);
+   MFA_CHECK_LAUNCH("k_unpack");
+   return 0;
+}
+
+extern "C" int mfem_amd_shared_accumulate(int64_t nuniq, const int *unq_ldof, const int *unq_shr_i,
+                                          const int *unq_shr_j, const double *shr_buf, double *y,
+                                          void *stream)
+{
+   if (nuniq == 0) { return 0; }
+   MFA_REQUIRE(nuniq > 0 && unq_ldof && unq_shr_i && unq_shr_j && shr_buf && y, "shared_accumulate: bad arguments");
+   k_accumulate<<<dim3(grid_for(nuniq)), dim3(256), 0, as_stream(stream)>>>(nuniq, unq_ldof, unq_shr_i, unq_shr_j, shr_buf, y);
+   MFA_CHECK_LAUNCH("k_accumulate");
    return 0;
 }

@@ -136,10 +136,10 @@ k_pcg_init(const int64_t n, const double *__restrict__ b, const double *__restri
 // (linalg/solvers.cpp:895-928).
 __global__ void __launch_bounds__(256)
 k_pcg_init_scalars(const int nb, const double *__restrict__ partials, PcgState *st,
-                   double *__restrict__ hist)
+                   double *__restrict__ hist, const double *__restrict__ gsum)
 {
    __shared__ double s4[4];
-   const double nom = final_sum(partials, nb, s4);
+   const double nom = gsum ? *gsum : final_sum(partials, nb, s4);   // gsum: all-reduced sum
    if (threadIdx.x == 0)
    {
       st->nom = st->nom0 = st->betanom = nom;
@@ -155,11 +155,12 @@ k_pcg_init_scalars(const int nb, const double *__restrict__ partials, PcgState *
 // den = (d, A d) after the first/each operator application (linalg/solvers.cpp:931-949,
 // 1010-1025); nom <- betanom at the end of an iteration.
 __global__ void __launch_bounds__(256)
-k_pcg_den_scalars(const int nb, const double *__restrict__ partials, PcgState *st, const int first)
+k_pcg_den_scalars(const int nb, const double *__restrict__ partials, PcgState *st, const int first,
+                  const double *__restrict__ gsum)
 {
    __shared__ double s4[4];
    if (st->done) { return; }
-   const double den = final_sum(partials, nb, s4);
+   const double den = gsum ? *gsum : final_sum(partials, nb, s4);
    if (threadIdx.x == 0)
    {
       st->den = den;
@@ -198,11 +199,11 @@ k_pcg_update(const int64_t n, const PcgState *__restrict__ st, const double *__r
 // betanom, convergence test, iteration count, beta (linalg/solvers.cpp:963-1000).
 __global__ void __launch_bounds__(256)
 k_pcg_beta_scalars(const int nb, const double *__restrict__ partials, PcgState *st,
-                   double *__restrict__ hist)
+                   double *__restrict__ hist, const double *__restrict__ gsum)
 {
    __shared__ double s4[4];
    if (st->done) { return; }
-   const double betanom = final_sum(partials, nb, s4);
+   const double betanom = gsum ? *gsum : final_sum(partials, nb, s4);
    if (threadIdx.x == 0)
    {
       const int i = st->iter + 1;        // the iteration whose update just ran
@@ -299,20 +300,34 @@ extern "C" int mfem_amd_jacobi_apply(int64_t n, const double *dinv, const double
 }
 
 // y = A x for the constrained PA operator; optionally the partial sums of (w, y).
-static int constrained_mult(const mfem_amd_pa_operator *op, const double *x, double *y,
-                            const double *w, double *partials, int nb, const int *skip,
-                            hipStream_t s)
+// With a communicator this is RAPOperator(P, A, P) (linalg/operator.cpp:433) on vectors that
+// live on the local L-dofs with non-owned (ghost) entries kept at zero: forward = P fills the
+// ghost entries of x from their owners, reverse = P^T adds the ghost entries of y into the
+// owners and zeroes them.  The (w, y) partials are taken BEFORE the reverse exchange, over
+// all local dofs: sum_ranks (P w)^T A_L (P w) = w^T P^T A P w.
+static int constrained_mult(const mfem_amd_pa_operator *op, const mfem_amd_comm *comm,
+                            double *x, double *y, const double *w, double *partials, int nb,
+                            const int *skip, hipStream_t s)
 {
    const bool ess = op->ness > 0;
    const int *gm = ess ? op->masked_gather_map : op->gather_map;
    MFA_REQUIRE(gm, "pa operator: %s is NULL", ess ? "masked_gather_map" : "gather_map");
    MFA_REQUIRE(!ess || op->ess_marker, "pa operator: ess_marker is NULL");
    MFA_REQUIRE(op->yE && op->offsets && op->indices && op->pa_data, "pa operator: null array");
+   if (comm)
+   {
+      if (int rc = comm->forward(comm->ctx, x, (void*)s)) { set_error("comm forward exchange failed (%d)", rc); return rc; }
+   }
    // NOTE: the element kernel is not gated by `skip`: after convergence it only rewrites
    // the work E-vector, and the gated transpose-gather leaves y untouched.
    if (int rc = pa_apply_L2E(op->kind, op->pa_layout, op->D1D, op->Q1D, op->ne, op->B, op->G, op->pa_data, gm, x, op->yE, s)) { return rc; }
-   return scatter_dot(op->ndofs, op->offsets, op->indices, op->yE, y, ess ? op->ess_marker : nullptr,
-                      x, w, partials, nb, skip, s);
+   if (int rc = scatter_dot(op->ndofs, op->offsets, op->indices, op->yE, y, ess ? op->ess_marker : nullptr,
+                            x, w, partials, nb, skip, s)) { return rc; }
+   if (comm)
+   {
+      if (int rc = comm->reverse(comm->ctx, y, (void*)s)) { set_error("comm reverse exchange failed (%d)", rc); return rc; }
+   }
+   return 0;
 }
 
 extern "C" int mfem_amd_pa_constrained_mult(const mfem_amd_pa_operator *op, const double *x,
@@ -322,27 +337,35 @@ extern "C" int mfem_amd_pa_constrained_mult(const mfem_amd_pa_operator *op, cons
    MFA_REQUIRE(x != y, "pa_constrained_mult: x and y must not alias");
    const unsigned nb = (unsigned)((op->ndofs + 255)/256);
    if (op->ndofs == 0) { return 0; }
-   return constrained_mult(op, x, y, nullptr, nullptr, (int)nb, nullptr, as_stream(stream));
+   return constrained_mult(op, nullptr, const_cast<double*>(x), y, nullptr, nullptr, (int)nb, nullptr, as_stream(stream));
+}
+
+extern "C" int mfem_amd_pa_par_mult(const mfem_amd_pa_operator *op, const mfem_amd_comm *comm,
+                                    double *x, double *y, void *stream)
+{
+   MFA_REQUIRE(op && comm && comm->forward && comm->reverse && x && y && x != y, "pa_par_mult: bad arguments");
+   const unsigned nb = (unsigned)((op->ndofs + 255)/256);
+   return constrained_mult(op, comm, x, y, nullptr, nullptr, (int)(nb ? nb : 1), nullptr, as_stream(stream));
 }
 
 static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1)/a*a; }
 
 extern "C" int64_t mfem_amd_pcg_workspace_bytes(int64_t n, int max_iter)
 {
-   // r, d, z | partials | hist | state
+   // r, d, z | partials | hist | state | global-sum slot
    return 3*align_up(n*8, 256) + align_up(RED_BLOCKS_MAX*8, 256) +
-          align_up(((int64_t)max_iter + 2)*8, 256) + 256;
+          align_up(((int64_t)max_iter + 2)*8, 256) + 256 + 256;
 }
 
-extern "C" int mfem_amd_pcg_pa(const mfem_amd_pa_operator *op, const double *dinv,
-                               const double *b, double *x, double rel_tol, double abs_tol,
-                               int max_iter, int check_every, void *workspace,
-                               mfem_amd_pcg_result *result, double *hist, void *stream)
+static int pcg_impl(const mfem_amd_pa_operator *op, const mfem_amd_comm *comm, const double *dinv,
+                    const double *b, double *x, double rel_tol, double abs_tol, int max_iter,
+                    int check_every, void *workspace, mfem_amd_pcg_result *result, double *hist,
+                    hipStream_t s)
 {
    MFA_REQUIRE(op && b && x && workspace && result, "pcg_pa: bad arguments");
    MFA_REQUIRE(max_iter >= 0, "pcg_pa: max_iter < 0");
+   MFA_REQUIRE(!comm || (comm->allreduce_sum && comm->forward && comm->reverse), "pcg_pa_par: incomplete communicator");
    if (check_every < 1) { check_every = 1; }
-   hipStream_t s = as_stream(stream);
    const int64_t n = op->ndofs;
    char *ws = (char*)workspace;
    double *r = (double*)ws; ws += align_up(n*8, 256);
@@ -350,7 +373,9 @@ extern "C" int mfem_amd_pcg_pa(const mfem_amd_pa_operator *op, const double *din
    double *z = (double*)ws; ws += align_up(n*8, 256);
    double *partials = (double*)ws; ws += align_up(RED_BLOCKS_MAX*8, 256);
    double *dhist = (double*)ws; ws += align_up(((int64_t)max_iter + 2)*8, 256);
-   PcgState *st = (PcgState*)ws;
+   PcgState *st = (PcgState*)ws; ws += 256;
+   double *gsum = (double*)ws;
+   const double *gs = comm ? gsum : nullptr;
 
    PcgState h = {};
    h.max_iter = max_iter; h.rel_tol = rel_tol; h.abs_tol = abs_tol;
@@ -358,13 +383,25 @@ extern "C" int mfem_amd_pcg_pa(const mfem_amd_pa_operator *op, const double *din
 
    const int nb = red_blocks(n);
    const unsigned sg = stream_grid(n);
+   // local partials -> one local sum -> all-reduce (InnerProduct(comm,...), linalg/vector.hpp:773-779)
+   auto global_sum = [&]() -> int
+   {
+      if (!comm) { return 0; }
+      k_dot_final<<<dim3(1), dim3(256), 0, s>>>(nb, partials, gsum);
+      if (int rc = check_hip(hipGetLastError(), "k_dot_final")) { return rc; }
+      if (int rc = comm->allreduce_sum(comm->ctx, gsum, 1, (void*)s)) { set_error("comm all-reduce failed (%d)", rc); return rc; }
+      return 0;
+   };
+
    k_pcg_init<<<dim3(nb), dim3(256), 0, s>>>(n, b, dinv, x, r, d, partials);
    MFA_CHECK_LAUNCH("k_pcg_init");
-   k_pcg_init_scalars<<<dim3(1), dim3(256), 0, s>>>(nb, partials, st, dhist);
+   if (int rc = global_sum()) { return rc; }
+   k_pcg_init_scalars<<<dim3(1), dim3(256), 0, s>>>(nb, partials, st, dhist, gs);
    MFA_CHECK_LAUNCH("k_pcg_init_scalars");
    // z = A d; den = (z, d)
-   if (int rc = constrained_mult(op, d, z, d, partials, nb, &st->done, s)) { return rc; }
-   k_pcg_den_scalars<<<dim3(1), dim3(256), 0, s>>>(nb, partials, st, 1);
+   if (int rc = constrained_mult(op, comm, d, z, d, partials, nb, &st->done, s)) { return rc; }
+   if (int rc = global_sum()) { return rc; }
+   k_pcg_den_scalars<<<dim3(1), dim3(256), 0, s>>>(nb, partials, st, 1, gs);
    MFA_CHECK_LAUNCH("k_pcg_den_scalars");
 
    // The reference's loop body runs at least once, even for max_iter == 0.
@@ -381,11 +418,13 @@ extern "C" int mfem_amd_pcg_pa(const mfem_amd_pa_operator *op, const double *din
       for (int k = 0; k < batch; k++)
       {
          k_pcg_update<<<dim3(nb), dim3(256), 0, s>>>(n, st, dinv, d, x, r, z, partials);
-         k_pcg_beta_scalars<<<dim3(1), dim3(256), 0, s>>>(nb, partials, st, dhist);
+         if (int rc = global_sum()) { return rc; }
+         k_pcg_beta_scalars<<<dim3(1), dim3(256), 0, s>>>(nb, partials, st, dhist, gs);
          k_pcg_dir<<<dim3(sg), dim3(256), 0, s>>>(n, st, z, d);
          MFA_CHECK_LAUNCH("pcg iteration kernels");
-         if (int rc = constrained_mult(op, d, z, d, partials, nb, &st->done, s)) { return rc; }
-         k_pcg_den_scalars<<<dim3(1), dim3(256), 0, s>>>(nb, partials, st, 0);
+         if (int rc = constrained_mult(op, comm, d, z, d, partials, nb, &st->done, s)) { return rc; }
+         if (int rc = global_sum()) { return rc; }
+         k_pcg_den_scalars<<<dim3(1), dim3(256), 0, s>>>(nb, partials, st, 0, gs);
          MFA_CHECK_LAUNCH("k_pcg_den_scalars");
       }
       launched += batch;
@@ -403,4 +442,23 @@ extern "C" int mfem_amd_pcg_pa(const mfem_amd_pa_operator *op, const double *din
       if (int rc = check_hip(hipStreamSynchronize(s), "hipStreamSynchronize")) { return rc; }
    }
    return 0;
+}
+
+extern "C" int mfem_amd_pcg_pa(const mfem_amd_pa_operator *op, const double *dinv,
+                               const double *b, double *x, double rel_tol, double abs_tol,
+                               int max_iter, int check_every, void *workspace,
+                               mfem_amd_pcg_result *result, double *hist, void *stream)
+{
+   return pcg_impl(op, nullptr, dinv, b, x, rel_tol, abs_tol, max_iter, check_every, workspace, result,
+                   hist, as_stream(stream));
+}
+
+extern "C" int mfem_amd_pcg_pa_par(const mfem_amd_pa_operator *op, const mfem_amd_comm *comm,
+                                   const double *dinv, const double *b, double *x, double rel_tol,
+                                   double abs_tol, int max_iter, int check_every, void *workspace,
+                                   mfem_amd_pcg_result *result, double *hist, void *stream)
+{
+   MFA_REQUIRE(comm, "pcg_pa_par: comm is NULL");
+   return pcg_impl(op, comm, dinv, b, x, rel_tol, abs_tol, max_iter, check_every, workspace, result,
+                   hist, as_stream(stream));
 }

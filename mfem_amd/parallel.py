@@ -1,0 +1,274 @@
+"""Multi-GPU host layer: box partition of a Cartesian hex mesh, shared-dof tables and the
+exchange that plugs into the C ABI's ``mfem_amd_comm`` (include/mfem_amd.h).
+
+Reference counterparts (semantics restated from the text; the parallel reference cannot be
+built here -- no MPI/hypre/METIS):
+  * ParMesh element partition: ``Mesh::CartesianPartitioning`` (mesh/mesh.cpp:8952), one box
+    per rank, rank = rx + PX*(ry + PY*rz).
+  * true-dof ownership: master of a dof's group = lowest rank among the sharers
+    (general/communication.cpp:120-124, communication.hpp:195-203).
+  * P / P^T: ``DeviceConformingProlongationOperator::Mult / MultTranspose``
+    (fem/pfespace.cpp:5401-5447, 5503-5539): pack ``shr_buf[i] = x[shr_ltdof[i]]``, one message
+    per neighbour each way, unpack ``y[ext_ldof[i]] = ext_buf[i]``; reverse direction with the
+    deterministic CSR accumulate (``unq_ltdof / unq_shr_i / unq_shr_j``, :5475-5494).
+  * global dot: local dot + all-reduce of ONE double (linalg/vector.hpp:773-779).
+
+MI355X mapping: one process per GPU; the transport is ``torch.distributed`` -- backend
+"nccl" is RCCL, so the grouped isend/irecv below become one ncclGroupStart/ncclSend/ncclRecv/
+ncclGroupEnd per exchange and, with <= 7 face/edge/corner neighbours per direction on a
+2x2x2 grid, every neighbour pair has its own xGMI link.  Messages are tiny (a face of a
+54^3 p=4 box is 47 089 doubles = 377 KB), so the exchange is latency-bound; the all-reduce
+carries one double.  Vectors live on local L-dofs with ghost entries kept at zero, so no
+T-vector <-> L-vector copies exist at all (the reference copies through ``ltdof_ldof``).
+The pack/unpack/accumulate kernels are HIP (C ABI); with the "gloo" backend (CPU tests, or
+several ranks sharing one GPU) buffers are staged through host memory.
+"""
+import ctypes as C
+import itertools
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .cartesian import CartesianProblem
+
+
+def process_grid(world):
+    """Box process grid for `world` ranks (as cubic as possible, x fastest)."""
+    best = None
+    for px in range(1, world + 1):
+        if world % px:
+            continue
+        for py in range(1, world//px + 1):
+            if (world//px) % py:
+                continue
+            pz = world//(px*py)
+            key = (max(px, py, pz) - min(px, py, pz), -px, -py)
+            if best is None or key < best[0]:
+                best = (key, (px, py, pz))
+    return best[1]
+
+
+class BoxPartition:
+    """Local problem and shared-dof tables of rank `rank` in a (PX,PY,PZ) box grid with
+    n = (nx,ny,nz) elements per rank and H1 order p."""
+
+    def __init__(self, p, n, pgrid, rank, extent=(1.0, 1.0, 1.0)):
+        self.p, self.n, self.pgrid, self.rank = p, tuple(n), tuple(pgrid), rank
+        PX, PY, PZ = pgrid
+        self.coord = (rank % PX, (rank//PX) % PY, rank//(PX*PY))
+        gn = (PX*n[0], PY*n[1], PZ*n[2])
+        origin = tuple(self.coord[d]*n[d] for d in range(3))
+        self.prob = CartesianProblem(p, n[0], n[1], n[2], extent[0], extent[1], extent[2], origin=origin, global_n=gn)
+        n1 = self.prob.n1
+        has_lo = [self.coord[d] > 0 for d in range(3)]
+        has_hi = [self.coord[d] < pgrid[d] - 1 for d in range(3)]
+        self.has_lo, self.has_hi = has_lo, has_hi
+
+        def index_set(off):
+            """local L-dof ids of the set shared with the neighbour at offset `off`, in
+            lexicographic (z slowest) order -- the same order on both sides"""
+            rng = []
+            for d in range(3):
+                if off[d] == 1:
+                    rng.append(np.array([n1[d] - 1]))
+                elif off[d] == -1:
+                    rng.append(np.array([0]))
+                else:
+                    rng.append(np.arange(1 if has_lo[d] else 0, n1[d]))
+            ix, iy, iz = rng
+            ids = ix[None, None, :] + n1[0]*(iy[None, :, None] + n1[1]*iz[:, None, None])
+            return ids.reshape(-1).astype(np.int32)
+
+        def nbr_rank(off):
+            c = [self.coord[d] + off[d] for d in range(3)]
+            return c[0] + PX*(c[1] + PY*c[2])
+
+        # owner side ("shr", upper neighbours) and ghost side ("ext", lower neighbours),
+        # neighbours sorted by rank (fixed accumulate order)
+        self.upper, self.lower = [], []
+        for off in itertools.product((0, 1), repeat=3):
+            if any(off) and all(has_hi[d] for d in range(3) if off[d]):
+                self.upper.append((nbr_rank(off), index_set(off)))
+        for off in itertools.product((0, -1), repeat=3):
+            if any(off) and all(has_lo[d] for d in range(3) if off[d]):
+                self.lower.append((nbr_rank(off), index_set(off)))
+        self.upper.sort(key=lambda t: t[0])
+        self.lower.sort(key=lambda t: t[0])
+        cat = lambda lst: (np.concatenate([a for _, a in lst]) if lst else np.zeros(0, np.int32)).astype(np.int32)
+        self.shr_ltdof = cat(self.upper)          # owned dofs sent to sharers (repeats allowed)
+        self.ext_ldof = cat(self.lower)           # ghost dofs (each appears exactly once)
+        self.shr_sizes = [len(a) for _, a in self.upper]
+        self.ext_sizes = [len(a) for _, a in self.lower]
+        assert len(np.unique(self.ext_ldof)) == len(self.ext_ldof)
+        # CSR for the deterministic accumulate: unique owned-shared dof -> positions in shr_buf
+        order = np.argsort(self.shr_ltdof, kind="stable")
+        uniq, counts = np.unique(self.shr_ltdof, return_counts=True)
+        self.unq_ltdof = uniq.astype(np.int32)
+        self.unq_shr_i = np.zeros(len(uniq) + 1, np.int32)
+        np.cumsum(counts, out=self.unq_shr_i[1:])
+        self.unq_shr_j = order.astype(np.int32)   # ascending buffer position = ascending neighbour rank
+        self.ghost = np.zeros(self.prob.ndofs, bool)
+        self.ghost[self.ext_ldof] = True
+        self.n_owned = int(self.prob.ndofs - self.ghost.sum())
+
+    def local_to_global(self):
+        """global lexicographic dof id of every local L-dof (tests)."""
+        p, n1 = self.p, self.prob.n1
+        PX, PY, PZ = self.pgrid
+        g1 = (p*PX*self.n[0] + 1, p*PY*self.n[1] + 1, p*PZ*self.n[2] + 1)
+        o = [self.coord[d]*self.n[d]*p for d in range(3)]
+        ix, iy, iz = np.arange(n1[0]) + o[0], np.arange(n1[1]) + o[1], np.arange(n1[2]) + o[2]
+        return (ix[None, None, :] + g1[0]*(iy[None, :, None] + g1[1]*iz[:, None, None])).reshape(-1), g1
+
+    def essential_marker(self):
+        """1 = essential & owned, 2 = essential ghost copy, 0 otherwise; plus the dof list."""
+        ess = self.prob.boundary_dofs()
+        m = np.zeros(self.prob.ndofs, np.uint8)
+        m[ess] = 1
+        m[ess[self.ghost[ess]]] = 2
+        return m, ess
+
+
+class Exchange:
+    """P / P^T / all-reduce on top of torch.distributed.  `device` is a torch device; with
+    CPU tensors (tests) the index kernels are torch ops, with CUDA tensors they are the HIP
+    kernels of the C ABI called on raw pointers."""
+
+    def __init__(self, part, device, group=None):
+        self.part, self.device, self.group = part, torch.device(device), group
+        self.on_gpu = self.device.type == "cuda"
+        self.stage = self.on_gpu and dist.is_initialized() and dist.get_backend(group) == "gloo"
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        self.shr_ltdof, self.ext_ldof = t(part.shr_ltdof), t(part.ext_ldof)
+        self.unq_ltdof, self.unq_shr_i, self.unq_shr_j = t(part.unq_ltdof), t(part.unq_shr_i), t(part.unq_shr_j)
+        self.shr_buf = torch.zeros(max(1, len(part.shr_ltdof)), dtype=torch.float64, device=self.device)
+        self.ext_buf = torch.zeros(max(1, len(part.ext_ldof)), dtype=torch.float64, device=self.device)
+        if self.stage:
+            self.shr_host = torch.zeros_like(self.shr_buf, device="cpu").pin_memory()
+            self.ext_host = torch.zeros_like(self.ext_buf, device="cpu").pin_memory()
+        if self.on_gpu:
+            from . import capi
+            self.capi = capi
+        self._cb_keep = None
+        self._sum_views = {}
+
+    # -- index kernels ---------------------------------------------------------------
+    def _ptr(self, v):
+        return v if isinstance(v, int) else v.data_ptr()
+
+    def _pack(self, idx, v, buf, stream):
+        if self.on_gpu:
+            self.capi.call("mfem_amd_shared_pack", idx.numel(), C.c_void_p(idx.data_ptr()), C.c_void_p(self._ptr(v)),
+                           C.c_void_p(buf.data_ptr()), stream)
+        else:
+            buf[:idx.numel()] = v[idx.long()]
+
+    def _unpack(self, idx, buf, v, stream):
+        if self.on_gpu:
+            self.capi.call("mfem_amd_shared_unpack", idx.numel(), C.c_void_p(idx.data_ptr()), C.c_void_p(buf.data_ptr()),
+                           C.c_void_p(self._ptr(v)), stream)
+        else:
+            v[idx.long()] = buf[:idx.numel()]
+
+    def _accumulate(self, v, stream):
+        nu = self.unq_ltdof.numel()
+        if nu == 0:
+            return
+        if self.on_gpu:
+            self.capi.call("mfem_amd_shared_accumulate", nu, C.c_void_p(self.unq_ltdof.data_ptr()),
+                           C.c_void_p(self.unq_shr_i.data_ptr()), C.c_void_p(self.unq_shr_j.data_ptr()),
+                           C.c_void_p(self.shr_buf.data_ptr()), C.c_void_p(self._ptr(v)), stream)
+        else:
+            off = self.unq_shr_i.tolist()
+            for i, k in enumerate(self.unq_ltdof.tolist()):     # fixed order, small (tests)
+                s = v[k]
+                for j in range(off[i], off[i + 1]):
+                    s = s + self.shr_buf[self.unq_shr_j[j]]
+                v[k] = s
+
+    def _zero_ghosts(self, v, stream):
+        n = self.ext_ldof.numel()
+        if n == 0:
+            return
+        if self.on_gpu:
+            self.capi.call("mfem_amd_set_subvector", n, C.c_void_p(self.ext_ldof.data_ptr()), None, 0.0,
+                           C.c_void_p(self._ptr(v)), stream)
+        else:
+            v[self.ext_ldof.long()] = 0.0
+
+    # -- transport -------------------------------------------------------------------
+    def _transfer(self, send_buf, send_list, send_sizes, recv_buf, recv_list, recv_sizes, send_host=None, recv_host=None):
+        if not send_list and not recv_list:
+            return
+        if self.stage:
+            torch.cuda.current_stream().synchronize()
+            send_host.copy_(send_buf)
+            sb, rb = send_host, recv_host
+        else:
+            sb, rb = send_buf, recv_buf
+        ops, o = [], 0
+        for (peer, _), sz in zip(recv_list, recv_sizes):
+            ops.append(dist.P2POp(dist.irecv, rb[o:o + sz], peer, self.group)); o += sz
+        o = 0
+        for (peer, _), sz in zip(send_list, send_sizes):
+            ops.append(dist.P2POp(dist.isend, sb[o:o + sz], peer, self.group)); o += sz
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+        if self.stage:
+            recv_buf.copy_(recv_host)
+
+    def forward(self, v, stream=None):
+        """P: ghost entries of v := owner values.  v: tensor or raw device pointer."""
+        p = self.part
+        self._pack(self.shr_ltdof, v, self.shr_buf, stream)
+        self._transfer(self.shr_buf, p.upper, p.shr_sizes, self.ext_buf, p.lower, p.ext_sizes,
+                       getattr(self, "shr_host", None), getattr(self, "ext_host", None))
+        self._unpack(self.ext_ldof, self.ext_buf, v, stream)
+
+    def reverse(self, v, stream=None):
+        """P^T: owners += ghost contributions (fixed neighbour order); ghosts := 0."""
+        p = self.part
+        self._pack(self.ext_ldof, v, self.ext_buf, stream)
+        self._transfer(self.ext_buf, p.lower, p.ext_sizes, self.shr_buf, p.upper, p.shr_sizes,
+                       getattr(self, "ext_host", None), getattr(self, "shr_host", None))
+        self._accumulate(v, stream)
+        self._zero_ghosts(v, stream)
+
+    def allreduce_sum(self, t):
+        if self.stage:
+            h = t.cpu()
+            dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, group=self.group)
+
+    # -- the C ABI communicator ---------------------------------------------------------
+    def make_comm(self, workspace):
+        """struct mfem_amd_comm whose callbacks run this exchange.  `workspace` is the torch
+        uint8 tensor handed to mfem_amd_pcg_pa_par (the all-reduce slot lives inside it)."""
+        from . import capi
+        AR, EX = capi.AR_FN, capi.EX_FN
+        self.error = None
+
+        def guard(fn):
+            def w(*a):
+                try:
+                    fn(*a)
+                    return 0
+                except Exception as e:                      # noqa: BLE001 -- must not unwind into C
+                    self.error = e
+                    return 1
+            return w
+
+        def allreduce(ctx, buf, n, stream):
+            off = buf - workspace.data_ptr()
+            key = (off, n)
+            if key not in self._sum_views:
+                self._sum_views[key] = workspace[off:off + 8*n].view(torch.float64)
+            self.allreduce_sum(self._sum_views[key])
+
+        cbs = (AR(guard(allreduce)), EX(guard(lambda ctx, v, s: self.forward(v, C.c_void_p(s)))),
+               EX(guard(lambda ctx, v, s: self.reverse(v, C.c_void_p(s)))))
+        self._cb_keep = cbs
+        return capi.Comm(None, cbs[0], cbs[1], cbs[2])

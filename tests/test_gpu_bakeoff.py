@@ -1,0 +1,119 @@
+"""-m gpu: the whole device pipeline (setup from nodes -> blocked pa_data -> diagonal ->
+Jacobi -> RHS -> device-resident PCG) against the known answers the reference itself
+produced for the CEED bake-off problems (tests/golden/baseline_anchors.json):
+PCG iteration count and ||X||_2 at ~1.2e5 dofs, p = 1..8, BP1/BP3/BP5.  Both are invariant
+under the dof permutation between MFEM's numbering and the driver's lexicographic one."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+ANCH = json.loads((Path(__file__).parent / "golden" / "baseline_anchors.json").read_text())
+
+
+@pytest.mark.parametrize("case", ANCH["cases"], ids=lambda c: f"{c['problem']}_p{c['p']}")
+def test_bakeoff_known_answers(case):
+    from mfem_amd import capi
+    from mfem_amd.bp import BakeoffProblem
+    capi.call("mfem_amd_init", 0)
+    p = case["p"]
+    n = 48//p
+    bp = BakeoffProblem(case["problem"], p, (n, n, n), "cuda:0")
+    assert (bp.ne, bp.ndofs, bp.D, bp.Q) == (case["NE"], case["dofs"], case["D1D"], case["Q1D"])
+    b = bp.rhs_unit_source()
+    X, res, hist = bp.pcg(b, 1e-12, max_iter=2000, check_every=16, want_hist=True)
+    torch.cuda.synchronize()
+    nX = float(torch.linalg.vector_norm(X).item())
+    # ||X|| : 1e-10 relative (CG at rel tol 1e-12 leaves an error of that order)
+    assert abs(nX - case["norm_X"]) < 1e-9*case["norm_X"], (nX, case["norm_X"])
+    # Iteration count at THIS tolerance (rel 1e-12 on sqrt((Br,r)), i.e. a 1e-24 reduction of
+    # (Br,r)) is decided inside the rounding-noise floor of double-precision CG: the last
+    # residuals are ~1e-28 and depend on the summation order of the dot products (the
+    # reference sums sequentially on one core, general/reducers.hpp:589-592).  Equal counts
+    # are required unless the run is provably in that regime; then +-1 (or a stagnation
+    # plateau, <= 10 %) is accepted.  Exact equality at ex1's tolerance is asserted against
+    # the oracle in test_iteration_count_equals_oracle below.
+    if res.iterations != case["pcg_its"]:
+        assert hist[min(res.iterations, case["pcg_its"]) - 1] < 1e-22*hist[0]
+        assert abs(res.iterations - case["pcg_its"]) <= max(1, case["pcg_its"]//10), (res.iterations, case["pcg_its"])
+    assert res.converged == 1
+
+
+@pytest.mark.parametrize("problem", ["bp1", "bp3", "bp5"])
+@pytest.mark.parametrize("p", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_iteration_count_equals_oracle(problem, p):
+    """ex1's stopping rule (PCG(...,1e-12,0): rel_tol 1e-6 on sqrt((Br,r)), examples/ex1.cpp:251):
+    the device solve and the CPU oracle (the reference's summation order) stop at the same
+    iteration, with the same (B r, r) history (tolerances below) and the same solution to 1e-8."""
+    import oracle_lib as orc
+    from mfem_amd import capi
+    from mfem_amd.bp import BakeoffProblem
+    from mfem_amd.tables import bakeoff_tables
+    capi.call("mfem_amd_init", 0)
+    n = max(2, 20//p)
+    bp = BakeoffProblem(problem, p, (n, n, n), "cuda:0")
+    kind, D, Q, B, G, Bn, Gn, W = bakeoff_tables(problem, p)
+    pr, ne = bp.prob, bp.ne
+    J = np.zeros(9*Q**3*ne)
+    orc.lib.orc_jacobians_3d(2, Q, ne, Bn, Gn, pr.nodes_E, J)
+    if kind:
+        pa = np.zeros(6*Q**3*ne); orc.lib.orc_diffusion_setup_3d(Q, 1, ne, W, J, np.ones(1), 1, pa)
+    else:
+        det = np.zeros(Q**3*ne); orc.lib.orc_det_3d(Q, ne, J, det)
+        pa = np.zeros(Q**3*ne); orc.lib.orc_mass_setup_3d(Q, ne, W, det, np.ones(1), 1, pa)
+    op = orc.Operator(kind, D, Q, ne, pr.ndofs, B, G, pa, pr.gather_map, pr.offsets, pr.indices, bp.ess_host)
+    b = bp.rhs_unit_source()
+    # RHS against the oracle's DomainLFIntegrator restatement (f = 1)
+    det = np.zeros(Q**3*ne); orc.lib.orc_det_3d(Q, ne, J, det)
+    bE = np.zeros(ne*D**3); orc.lib.orc_domain_lf_3d(D, Q, ne, B, W, det, 1.0, bE)
+    bo = np.zeros(pr.ndofs); orc.lib.orc_restriction_mult_transpose(pr.ndofs, pr.offsets, pr.indices, bE, bo, 0, 0)
+    bo[bp.ess_host] = 0.0
+    assert np.max(np.abs(b.cpu().numpy() - bo)) < 1e-13*np.max(np.abs(bo))
+    dinv = orc.jacobi_setup(op.diag(), bp.ess_host)
+    assert np.max(np.abs(bp.dinv().cpu().numpy() - dinv)) < 1e-12*np.max(np.abs(dinv))
+    Xo, its, ho, conv = op.pcg(bo, dinv, 1e-6)
+    X, res, h = bp.pcg(b, 1e-6, check_every=5, want_hist=True)
+    assert res.iterations == its and bool(res.converged) == conv
+    # (B r, r) history: CG amplifies the dot-product-order rounding by cond(A) as it converges
+    big = ho > 1e-6*ho[0]
+    assert np.max(np.abs(h[big] - ho[big])/ho[big]) < 1e-7
+    mid = ho > 1e-18*ho[0]                      # below: (B r, r) is pure rounding noise
+    assert np.max(np.abs(h[mid] - ho[mid])/ho[mid]) < 5e-2
+    assert np.max(np.abs(X.cpu().numpy() - Xo)) < 1e-8*np.max(np.abs(Xo))
+
+
+def test_operator_properties_at_scale():
+    """size-independent properties at ~1e6 dofs: symmetry, linearity, constants in the kernel
+    of the diffusion operator, sum(M 1) = volume."""
+    from mfem_amd import capi
+    from mfem_amd.bp import BakeoffProblem
+    capi.call("mfem_amd_init", 0)
+    dev = "cuda:0"
+    for prob, p in (("bp3", 4), ("bp1", 3), ("bp5", 6)):
+        n = max(2, round(1e6**(1/3)/p))
+        bp = BakeoffProblem(prob, p, (n, n, n), dev)
+        g = torch.Generator(device="cpu"); g.manual_seed(3)
+        x = torch.rand(bp.ndofs, dtype=torch.float64, generator=g).to(dev)
+        y = torch.rand(bp.ndofs, dtype=torch.float64, generator=g).to(dev)
+        Ax, Ay, Axy = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        bp.mult(x, Ax); bp.mult(y, Ay)
+        xy = 2.0*x - 3.0*y
+        bp.mult(xy, Axy)
+        torch.cuda.synchronize()
+        scale = float(torch.max(torch.abs(Ax)))
+        assert float(torch.max(torch.abs(Axy - (2.0*Ax - 3.0*Ay)))) < 1e-12*scale*10          # linearity
+        assert abs(float(torch.dot(y, Ax)) - float(torch.dot(x, Ay))) < 1e-12*abs(float(torch.dot(y, Ax)))*10  # symmetry
+        one = torch.ones_like(x)
+        A1 = torch.empty_like(x)
+        bp.mult(one, A1)
+        if bp.kind:
+            assert float(torch.max(torch.abs(A1))) < 1e-11*scale                              # A 1 = 0
+        else:
+            assert abs(float(torch.sum(A1)) - 1.0) < 1e-12                                   # volume of the unit cube
+        A2 = torch.empty_like(x)
+        bp.mult(x, A2)
+        assert torch.equal(A2, Ax)                                                           # bit-reproducible

@@ -1,0 +1,76 @@
+"""-m gpu: the partitioned solve through the C ABI (mfem_amd_pcg_pa_par + the exchange of
+mfem_amd/parallel.py), 2 ranks sharing cuda:0 over gloo (host-staged messages), against the
+serial device solve of the same global problem: identical iteration count, solution to 1e-10."""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _worker(rank, world, port, problem, p, n, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, str(ROOT))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mfem_amd import capi
+        from mfem_amd.bp import BakeoffProblem
+        from mfem_amd.parallel import BoxPartition, Exchange, process_grid
+        capi.call("mfem_amd_init", 0)
+        torch.cuda.set_device(0)
+        pg = process_grid(world)
+        part = BoxPartition(p, (n, n, n), pg, rank)
+        ex = Exchange(part, "cuda:0")
+        bp = BakeoffProblem(problem, p, (n, n, n), "cuda:0", part=part, exchange=ex)
+        b = bp.rhs_unit_source()
+        X, res, hist = bp.pcg(b, 1e-10, max_iter=1000, check_every=4, want_hist=True)
+        # serial solve of the global problem on the same GPU
+        sp = BakeoffProblem(problem, p, (pg[0]*n, pg[1]*n, pg[2]*n), "cuda:0")
+        Xs, rs, hs = sp.pcg(sp.rhs_unit_source(), 1e-10, max_iter=1000, check_every=4, want_hist=True)
+        torch.cuda.synchronize()
+        l2g, _ = part.local_to_global()
+        assert res.iterations == rs.iterations, (res.iterations, rs.iterations)
+        Xs_l = Xs.cpu().numpy()[l2g]
+        err = np.max(np.abs(X.cpu().numpy() - Xs_l))/np.max(np.abs(Xs_l))
+        assert err < 1e-10, err                     # owners AND ghosts consistent
+        big = hs > 1e-12*hs[0]              # below that the history is dot-order rounding noise
+        assert np.max(np.abs(hist[big] - hs[big])/hs[big]) < 1e-6
+        # operator apply: P^T A P x vs serial
+        xg = torch.rand(sp.ndofs, dtype=torch.float64, generator=torch.Generator().manual_seed(1)).cuda()
+        ys = torch.empty_like(xg); sp.mult(xg, ys)
+        xl = xg[torch.from_numpy(l2g).cuda()].clone()
+        xl[bp.ghost.long()] = 0.0
+        yl = torch.empty_like(xl); bp.mult(xl, yl)
+        torch.cuda.synchronize()
+        own = ~part.ghost
+        e2 = np.max(np.abs(yl.cpu().numpy()[own] - ys.cpu().numpy()[l2g][own]))/float(ys.abs().max())
+        assert e2 < 1e-12, e2
+        out.put((rank, "ok"))
+    except Exception:                                                        # noqa: BLE001
+        import traceback
+        out.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("problem,p,n", [("bp3", 3, 4), ("bp1", 2, 5)])
+def test_two_ranks_match_serial(problem, p, n):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 29700 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, problem, p, n, out)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = [out.get(timeout=110) for _ in range(2)]
+    for pr in procs:
+        pr.join(30)
+    bad = [m for _, m in res if m != "ok"]
+    assert not bad, bad[0]
