@@ -24,37 +24,9 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec); ~6.3 TB/s achievable
-
-
-def gl_rule(n):
-    """Gauss-Legendre on [0,1] (numpy; host-side table for the benchmark inputs)."""
-    x, w = np.polynomial.legendre.leggauss(n)
-    return 0.5*(x + 1.0), 0.5*w
-
-
-def gll_points(n):
-    """Gauss-Lobatto points on [0,1]: endpoints + roots of P'_{n-1}."""
-    if n == 2:
-        return np.array([0.0, 1.0])
-    c = np.zeros(n); c[-1] = 1.0
-    r = np.polynomial.legendre.Legendre(c).deriv().roots()
-    return 0.5*(np.concatenate(([-1.0], np.sort(r.real), [1.0])) + 1.0)
-
-
-def lagrange_tables(nodes, pts):
-    """B[q + Q*d], G[q + Q*d] of the Lagrange basis on `nodes` at `pts` (barycentric)."""
-    n, Q = len(nodes), len(pts)
-    B, G = np.zeros((n, Q)), np.zeros((n, Q))
-    for d in range(n):
-        others = np.delete(nodes, d)
-        denom = np.prod(nodes[d] - others)
-        for q, y in enumerate(pts):
-            B[d, q] = np.prod(y - others)/denom
-            s = 0.0
-            for k in range(n - 1):
-                s += np.prod(np.delete(y - others, k))
-            G[d, q] = s/denom
-    return B.reshape(-1).copy(), G.reshape(-1).copy()
+# HBM bytes per launch of the dominant kernel from the PMC passes (profiles/r1/pmc_*.txt):
+# TCC_EA0_RDREQ (128 B per request for wide reads, the guide's gfx950 correction) + WRREQ*64 B.
+TRAFFIC_BYTES = {}
 
 
 def algorithmic_bytes(kind, D, Q, ne, ndofs):
@@ -71,7 +43,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--p", type=int, default=4)
-    ap.add_argument("--n", type=int, default=0, help="elements per direction per GPU (default: ~1e7 dofs)")
+    ap.add_argument("--elems", type=int, default=0, help="elements per direction per GPU (default: ~1e7 dofs per GPU)")
     ap.add_argument("--problem", default="bp3", choices=["bp1", "bp3", "bp5"])
     ap.add_argument("--cg-iters", type=int, default=50)
     ap.add_argument("--no-cpu", action="store_true")
@@ -81,73 +53,51 @@ def main():
     import torch
     import torch.distributed as dist
     from mfem_amd import capi
-    from mfem_amd.cartesian import CartesianProblem
+    from mfem_amd.bp import BakeoffProblem
+    from mfem_amd.parallel import BoxPartition, Exchange, process_grid
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MFEM_AMD_DIST_BACKEND") == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())   # rehearsal: ranks share GPUs
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     capi.call("mfem_amd_init", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        backend = os.environ.get("MFEM_AMD_DIST_BACKEND", "nccl")   # "gloo": rehearsal of N ranks on one GPU
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     p = args.p
-    D = p + 1
-    kind = 0 if args.problem == "bp1" else 1
-    Q = p + 1 if args.problem == "bp5" else p + 2
-    n = args.n or max(1, round((1.0e7)**(1.0/3.0)/p))
-    # weak scaling: every rank owns an n^3 box of a (px,py,pz) process grid
-    pg = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(world)
-    if pg is None:
-        raise SystemExit(f"unsupported world size {world}")
-    rx, ry, rz = rank % pg[0], (rank//pg[0]) % pg[1], rank//(pg[0]*pg[1])
-    prob = CartesianProblem(p, n, n, n, origin=(rx*n, ry*n, rz*n), global_n=(pg[0]*n, pg[1]*n, pg[2]*n))
-    ne, ndofs = prob.ne, prob.ndofs
-
-    nodes = gll_points(D)
-    if args.problem == "bp5":
-        qx = gll_points(Q)
-        # GLL weights: 2/(n(n-1) P_{n-1}(x)^2) on [-1,1], halved for [0,1]
-        c = np.zeros(Q); c[-1] = 1.0
-        qw = 1.0/(Q*(Q - 1)*np.polynomial.legendre.Legendre(c)(2*qx - 1)**2)
-    else:
-        qx, qw = gl_rule(Q)
-    B, G = lagrange_tables(nodes, qx)
-    Bn, Gn = lagrange_tables(np.array([0.0, 1.0]), qx)
-    W = (qw[None, None, :]*qw[None, :, None]*qw[:, None, None]).reshape(-1)
-
-    t = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a, dt)).to(dev)
-    ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
-    gm, off, ind = t(prob.gather_map), t(prob.offsets), t(prob.indices)
-    nodesE, Wd = t(prob.nodes_E), t(W)
-    LAYOUT = 1            # blocked pa_data layout (the product's own AssemblePA + AddMultPA)
-    pa = torch.zeros(capi.lib.mfem_amd_pa_data_size(kind, LAYOUT, Q, ne), dtype=torch.float64, device=dev)
-    one = torch.ones(1, dtype=torch.float64, device=dev)
-    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
+    n = args.elems or max(1, round((1.0e7)**(1.0/3.0)/p))
+    # weak scaling: every rank owns an n^3 box of the (PX,PY,PZ) process grid; shared dofs on
+    # the box interfaces are exchanged (P before, P^T after every operator application)
+    pg = process_grid(world)
     t0 = time.perf_counter()
-    capi.call("mfem_amd_pa_setup_from_nodes_3d", kind, 2, Q, 1, ne, Bn, Gn, ptr(Wd), ptr(nodesE), ptr(one), 1,
-              LAYOUT, ptr(pa), None, stream)
+    if world > 1:
+        part = BoxPartition(p, (n, n, n), pg, rank)
+        ex = Exchange(part, dev)
+        bp = BakeoffProblem(args.problem, p, (n, n, n), dev, part=part, exchange=ex)
+        owned = torch.tensor([part.n_owned], dtype=torch.float64, device=dev)
+        dist.all_reduce(owned)
+        total_dofs = int(owned.item())
+    else:
+        bp = BakeoffProblem(args.problem, p, (n, n, n), dev)
+        total_dofs = bp.ndofs
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
-    del nodesE
+    kind, D, Q, ne, ndofs = bp.kind, bp.D, bp.Q, bp.ne, bp.ndofs
 
     g = torch.Generator(device="cpu"); g.manual_seed(1 + rank)
     x = torch.rand(ndofs, dtype=torch.float64, generator=g).to(dev)
+    if world > 1 and bp.ghost.numel():
+        x[bp.ghost.long()] = 0.0
     y = torch.empty_like(x)
-    yE = torch.empty(ne*D**3, dtype=torch.float64, device=dev)
-
-    def l2e():
-        capi.call("mfem_amd_pa_apply_L2E", kind, LAYOUT, D, Q, ne, B, G, ptr(pa), ptr(gm), ptr(x), ptr(yE), stream)
-
-    def e2l():
-        capi.call("mfem_amd_restrict_scatter", ndofs, ptr(off), ptr(ind), ptr(yE), ptr(y), 0, 0, stream)
 
     def step():
-        l2e(); e2l()
+        bp.mult(x, y)
 
     def timed(fn, k):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -170,81 +120,65 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    torch.cuda.synchronize()
     el = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
-    total_dofs = ndofs*world
     value = total_dofs*args.steps/el/1e9
 
-    # per-kernel durations (HIP events on the launch stream), same K
-    t_l2e = timed(l2e, args.steps)/args.steps
-    t_e2l = timed(e2l, args.steps)/args.steps
+    # per-kernel durations on this rank (HIP events on the launch stream), same K
+    t_l2e = timed(lambda: bp.l2e(x), args.steps)/args.steps
+    t_e2l = timed(lambda: bp.e2l(y), args.steps)/args.steps
     b_l2e, b_e2l = algorithmic_bytes(kind, D, Q, ne, ndofs)
     roof = {"bound": "hbm", "kernel": "k_pa_apply (fused L->E gather + element kernel)",
             "achieved": b_l2e/t_l2e/1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": b_l2e/t_l2e/1e9/HBM_PEAK_GBS, "traffic": None,
+            "frac": b_l2e/t_l2e/1e9/HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES.get((args.problem, p, n)),
             "algorithmic_bytes_per_launch": b_l2e, "avg_launch_ms": t_l2e*1e3}
     t_apply = el/args.steps
     roof_apply = {"bound": "hbm", "achieved": (b_l2e + b_e2l)/t_apply/1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                  "frac": (b_l2e + b_e2l)/t_apply/1e9/HBM_PEAK_GBS, "algorithmic_bytes": b_l2e + b_e2l,
+                  "frac": (b_l2e + b_e2l)/t_apply/1e9/HBM_PEAK_GBS, "algorithmic_bytes_per_gpu": b_l2e + b_e2l,
                   "e2l_avg_launch_ms": t_e2l*1e3, "e2l_achieved_GBs": b_e2l/t_e2l/1e9}
 
     # Jacobi-PCG on the constrained operator, exactly cg_iters iterations (rel_tol = 0)
     cg = None
-    if world == 1 and args.cg_iters > 0:
-        ess = prob.boundary_dofs()
-        essd = t(ess)
-        marker = torch.zeros(ndofs, dtype=torch.uint8, device=dev)
-        masked = torch.empty(ne*D**3, dtype=torch.int32, device=dev)
-        capi.call("mfem_amd_set_marker", len(ess), ptr(essd), ptr(marker), stream)
-        capi.call("mfem_amd_mask_gather_map", ne*D**3, ptr(gm), ptr(marker), ptr(masked), stream)
-        dE = torch.zeros(ne*D**3, dtype=torch.float64, device=dev)
-        diag, dinv = torch.empty_like(x), torch.empty_like(x)
-        if kind:
-            capi.call("mfem_amd_pa_diffusion_diag_3d", D, Q, ne, 1, B, G, ptr(pa), LAYOUT, ptr(dE), stream)
-        else:
-            capi.call("mfem_amd_pa_mass_diag_3d", D, Q, ne, B, ptr(pa), LAYOUT, ptr(dE), stream)
-        capi.call("mfem_amd_restrict_scatter", ndofs, ptr(off), ptr(ind), ptr(dE), ptr(diag), 0, 1, stream)
-        capi.call("mfem_amd_jacobi_setup", ndofs, ptr(diag), 1.0, len(ess), ptr(essd), ptr(dinv), stream)
-        del dE
-        vp = lambda a: a.ctypes.data_as(C.c_void_p)
-        op = capi.PaOperator(kind, LAYOUT, D, Q, ne, ndofs, vp(B), vp(G), ptr(pa), ptr(gm), ptr(masked), ptr(off), ptr(ind),
-                             len(ess), ptr(essd), ptr(marker), ptr(yE))
+    if args.cg_iters > 0:
         rhs = torch.rand(ndofs, dtype=torch.float64, generator=g).to(dev)
-        rhs[essd.long()] = 0.0
-        ws = torch.empty(capi.lib.mfem_amd_pcg_workspace_bytes(ndofs, args.cg_iters), dtype=torch.uint8, device=dev)
-        sol = torch.empty_like(x)
-        res = capi.PcgResult()
-
-        def solve(iters):
-            capi.call("mfem_amd_pcg_pa", C.byref(op), ptr(dinv), ptr(rhs), ptr(sol), 0.0, 0.0, iters, iters,
-                      ptr(ws), C.byref(res), None, stream)
-
-        solve(3)
+        rhs[bp.ess.long()] = 0.0
+        if world > 1 and bp.ghost.numel():
+            rhs[bp.ghost.long()] = 0.0
+        bp.pcg(rhs, 0.0, max_iter=3, check_every=3)
         torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
         t0 = time.perf_counter()
-        solve(args.cg_iters)
+        _, res, _ = bp.pcg(rhs, 0.0, max_iter=args.cg_iters, check_every=args.cg_iters)
         torch.cuda.synchronize()
         tcg = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([tcg], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tcg = float(tt.item())
         it = res.iterations
         cg_bytes = (b_l2e + b_e2l + 96*ndofs)*it
-        cg = {"iters": it, "dofs_iter_per_s": ndofs*it/tcg, "ms_per_iter": tcg/it*1e3,
-              "hbm_frac": cg_bytes/tcg/1e9/HBM_PEAK_GBS, "final_nom": res.final_nom, "initial_nom": res.initial_nom}
+        cg = {"iters": it, "dofs_iter_per_s": total_dofs*it/tcg, "ms_per_iter": tcg/it*1e3,
+              "hbm_frac_per_gpu": cg_bytes/tcg/1e9/HBM_PEAK_GBS, "final_nom": res.final_nom, "initial_nom": res.initial_nom}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(kind, p, Q, B, G, Bn, Gn, W, args.cpu_seconds)
+        from mfem_amd.tables import bakeoff_tables
+        cpu = cpu_baseline(args.problem, p, args.cpu_seconds)
 
     if rank == 0:
         out = {"metric": "BP3 PA operator-apply GDOF/s (p=1..8) + CG DOFs*iter/s at 1/2/4/8 GPUs",
                "value": value, "unit": "GDOF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": el/args.steps*1e3, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": f"CEED {args.problem.upper()} PA operator apply (L->L), H1 p={p} "
+               "config": {"workload": f"CEED {args.problem.upper()} PA operator apply (L->L, P^T A P across GPUs), H1 p={p} "
                                       f"D1D={D} Q1D={Q}, Cartesian hex mesh {n}^3 per GPU",
-                          "elements_per_gpu": ne, "dofs_per_gpu": ndofs, "process_grid": list(pg)},
+                          "elements_per_gpu": ne, "local_dofs_per_gpu": ndofs, "global_dofs": total_dofs,
+                          "process_grid": list(pg)},
                "roofline": roof, "roofline_apply": roof_apply, "cg": cg, "cpu_baseline": cpu,
                "setup_s": setup_s}
         print(json.dumps(out))
@@ -252,14 +186,15 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(kind, p, Q, B, G, Bn, Gn, W, seconds):
+def cpu_baseline(problem, p, seconds):
     """The CPU oracle (oracle/pa_oracle.c, the restatement of MFEM's `-d cpu` PA path) on the
-    host cores: the same operator at the same order on a bounded sample (a 16^3 mesh),
+    host cores: the same operator at the same order on a bounded sample (a (64/p)^3 mesh),
     OpenMP over elements.  kind = "port"."""
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle_lib as orc
     from mfem_amd.cartesian import CartesianProblem
-    D = p + 1
+    from mfem_amd.tables import bakeoff_tables
+    kind, D, Q, B, G, Bn, Gn, W = bakeoff_tables(problem, p)
     n = max(2, 64//p)
     prob = CartesianProblem(p, n, n, n)
     ne, ndofs = prob.ne, prob.ndofs

@@ -17,8 +17,8 @@ for p in [int(a) for a in sys.argv[1].split(",")]:
     n = round(1e7**(1/3)/p)
     prob = CartesianProblem(p, n, n, n)
     ne, ndofs = prob.ne, prob.ndofs
-    qx, qw = bench.gl_rule(Q)
-    B, G = bench.lagrange_tables(bench.gll_points(D), qx)
+    from mfem_amd.tables import bakeoff_tables
+    _, _, _, B, G, _, _, _ = bakeoff_tables('bp3', p)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     gm = t(prob.gather_map)
     pa = torch.rand(capi.lib.mfem_amd_pa_data_size(1, 1, Q, ne), dtype=torch.float64, device=dev)

@@ -11,6 +11,7 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 import bench  # noqa: E402
+from mfem_amd import tables  # noqa: E402
 
 
 def run(problem, p, n, steps, which, layout=1):
@@ -23,16 +24,7 @@ def run(problem, p, n, steps, which, layout=1):
     Q = p + 1 if problem == "bp5" else p + 2
     prob = CartesianProblem(p, n, n, n)
     ne, ndofs = prob.ne, prob.ndofs
-    nodes = bench.gll_points(D)
-    if problem == "bp5":
-        qx = bench.gll_points(Q)
-        c = np.zeros(Q); c[-1] = 1.0
-        qw = 1.0/(Q*(Q - 1)*np.polynomial.legendre.Legendre(c)(2*qx - 1)**2)
-    else:
-        qx, qw = bench.gl_rule(Q)
-    B, G = bench.lagrange_tables(nodes, qx)
-    Bn, Gn = bench.lagrange_tables(np.array([0.0, 1.0]), qx)
-    W = (qw[None, None, :]*qw[None, :, None]*qw[:, None, None]).reshape(-1)
+    kind, D, Q, B, G, Bn, Gn, W = tables.bakeoff_tables(problem, p)
     t = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a, dt)).to(dev)
     ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
     gm, off, ind = t(prob.gather_map), t(prob.offsets), t(prob.indices)
