@@ -24,9 +24,15 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec); ~6.3 TB/s achievable
-# HBM bytes per launch of the dominant kernel from the PMC passes (profiles/r1/pmc_*.txt):
-# TCC_EA0_RDREQ (128 B per request for wide reads, the guide's gfx950 correction) + WRREQ*64 B.
-TRAFFIC_BYTES = {}
+# HBM bytes per launch of the dominant kernel from the PMC passes
+# (profiles/r1/bench_p4_pmc_hbm_traffic.txt, tools/pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in
+# separate rocprofv3 --pmc runs of this script, KiB per dispatch averaged over the timed
+# launches).  gfx950 correction of MI355X_MICROARCH.md (HBM section): FETCH_SIZE tallies the
+# 128-B requests of wide streaming reads at 64 B -> doubled; WRITE_SIZE is exact.
+#   k_pa_apply<1,5,6,...>: FETCH_SIZE 9.128e5 KiB, WRITE_SIZE 1.545e5 KiB
+#   -> 2*934.7e6 + 158.2e6 B = 2.028e9 B  (reads +4.3 % over the algorithmic 1.793e9 B,
+#      the rest is the E-vector store the fused-scatter design of DESIGN.md §8 would remove)
+TRAFFIC_BYTES = {("bp3", 4, 54): int(2*9.128e5*1024 + 1.545e5*1024)}
 
 
 def algorithmic_bytes(kind, D, Q, ne, ndofs):
