@@ -109,6 +109,16 @@ int mfem_amd_pa_setup_from_nodes_3d(int kind, int Dn, int Q1D, int coeffDim, int
 int64_t mfem_amd_pa_data_size(int kind, int pa_layout, int Q1D, int64_t ne); /* in doubles */
 int mfem_amd_pa_data_to_blocked(int kind, int Q1D, int64_t ne, const double *D,
                                 double *Dblocked, void *stream);
+int mfem_amd_pa_data_from_blocked(int kind, int Q1D, int64_t ne, const double *Dblocked,
+                                  double *D, void *stream);
+
+/* DomainLFIntegrator, device path (fem/integ/lininteg_domain.cpp:22-59 -> DLFEvalAssemble3D,
+ * fem/integ/lininteg_domain_kernels.hpp): yE(dx,dy,dz,e) += sum_q B(qx,dx) B(qy,dy) B(qz,dz)
+ * F(q,e) with F = W * f * detJ at the quadrature points ((Q^3, NE), what
+ * mfem_amd_pa_setup_from_nodes_3d(kind 0, pa_layout 0) produces for the coefficient f).
+ * Follow with mfem_amd_restrict_scatter.  B: HOST. */
+int mfem_amd_domain_lf_3d(int D1D, int Q1D, int64_t ne, const double *B, const double *F,
+                          double *yE, void *stream);
 
 /* ---- PA operator action ---------------------------------------------------------- */
 

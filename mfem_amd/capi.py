@@ -56,6 +56,8 @@ _SIGS = {
     "mfem_amd_pa_setup_from_nodes_3d": (cint, [cint, cint, cint, cint, i64, _hd, _hd, vp, vp, vp, cint, cint, vp, vp, vp]),
     "mfem_amd_pa_data_size": (i64, [cint, cint, cint, i64]),
     "mfem_amd_pa_data_to_blocked": (cint, [cint, cint, i64, vp, vp, vp]),
+    "mfem_amd_pa_data_from_blocked": (cint, [cint, cint, i64, vp, vp, vp]),
+    "mfem_amd_domain_lf_3d": (cint, [cint, cint, i64, vp, vp, vp, vp]),
     "mfem_amd_pa_diffusion_apply_3d": (cint, [cint, cint, i64, cint, _hd, _hd, vp, vp, vp, vp]),
     "mfem_amd_pa_mass_apply_3d": (cint, [cint, cint, i64, _hd, vp, vp, vp, vp]),
     "mfem_amd_pa_diffusion_diag_3d": (cint, [cint, cint, i64, cint, _hd, _hd, vp, cint, vp, vp]),

@@ -180,6 +180,59 @@ k_to_blocked(const int kind, const int Q, const int64_t n, const double *__restr
    Dout[blocked_index(kind, Q, e, q, c)] = Din[i];
 }
 
+// blocked layout -> MFEM layout (the inverse permutation)
+__global__ void __launch_bounds__(256)
+k_from_blocked(const int kind, const int Q, const int64_t n, const double *__restrict__ Dblk,
+               double *__restrict__ Dout)
+{
+   const int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x;
+   if (i >= n) { return; }
+   const int Q3 = Q*Q*Q, nc = kind ? 6 : 1;
+   const int q = (int)(i % Q3), c = (int)((i/Q3) % nc);
+   const int64_t e = i/((int64_t)Q3*nc);
+   Dout[i] = Dblk[blocked_index(kind, Q, e, q, c)];
+}
+
+// Domain linear form, one workgroup per element (runtime D, Q):
+// yE(dx,dy,dz,e) += sum_q B(qx,dx) B(qy,dy) B(qz,dz) F(q,e), F = W*f*detJ at the points,
+// contracted x, then y, then z through LDS.
+__global__ void __launch_bounds__(256)
+k_domain_lf(const int D, const int Q, const BasisT<MAX_DQ> bg, const double *__restrict__ F,
+            double *__restrict__ Y)
+{
+   extern __shared__ __align__(16) double dyn[];
+   const int Q3 = Q*Q*Q, D3 = D*D*D;
+   double *sB = dyn, *s0 = sB + Q*D, *s1 = s0 + Q3, *s2 = s1 + D*Q*Q;
+   const int tid = threadIdx.x, nt = blockDim.x;
+   const int64_t e = blockIdx.x;
+   for (int i = tid; i < Q*D; i += nt) { sB[i] = bg.b[i]; }
+   for (int i = tid; i < Q3; i += nt) { s0[i] = F[e*Q3 + i]; }
+   __syncthreads();
+   for (int i = tid; i < D*Q*Q; i += nt)         // [dx][qy][qz]
+   {
+      const int dx = i % D, qy = (i/D) % Q, qz = i/(D*Q);
+      double s = 0.0;
+      for (int qx = 0; qx < Q; qx++) { s += sB[qx*D + dx]*s0[qx + Q*(qy + Q*qz)]; }
+      s1[i] = s;
+   }
+   __syncthreads();
+   for (int i = tid; i < D*D*Q; i += nt)         // [dx][dy][qz]
+   {
+      const int dx = i % D, dy = (i/D) % D, qz = i/(D*D);
+      double s = 0.0;
+      for (int qy = 0; qy < Q; qy++) { s += sB[qy*D + dy]*s1[dx + D*(qy + Q*qz)]; }
+      s2[i] = s;
+   }
+   __syncthreads();
+   for (int i = tid; i < D3; i += nt)
+   {
+      const int dxy = i % (D*D), dz = i/(D*D);
+      double s = 0.0;
+      for (int qz = 0; qz < Q; qz++) { s += sB[qz*D + dz]*s2[dxy + D*D*qz]; }
+      Y[e*D3 + i] += s;
+   }
+}
+
 __global__ void __launch_bounds__(256)
 k_det(const int64_t n, const int Q3, const double *__restrict__ J, double *__restrict__ detJ)
 {
@@ -406,6 +459,32 @@ extern "C" int mfem_amd_pa_data_to_blocked(int kind, int Q1D, int64_t ne, const 
    const int64_t n = ne*(int64_t)(kind ? 6 : 1)*Q1D*Q1D*Q1D;
    k_to_blocked<<<dim3((unsigned)((n + 255)/256)), dim3(256), 0, as_stream(stream)>>>(kind, Q1D, n, D, Dblocked);
    MFA_CHECK_LAUNCH("k_to_blocked");
+   return 0;
+}
+
+extern "C" int mfem_amd_pa_data_from_blocked(int kind, int Q1D, int64_t ne, const double *Dblocked,
+                                             double *D, void *stream)
+{
+   if (ne == 0) { return 0; }
+   MFA_REQUIRE((kind == 0 || kind == 1) && Q1D >= 1 && Q1D <= MAX_Q1D && D && Dblocked && D != Dblocked,
+               "pa_data_from_blocked: bad arguments");
+   const int64_t n = ne*(int64_t)(kind ? 6 : 1)*Q1D*Q1D*Q1D;
+   k_from_blocked<<<dim3((unsigned)((n + 255)/256)), dim3(256), 0, as_stream(stream)>>>(kind, Q1D, n, Dblocked, D);
+   MFA_CHECK_LAUNCH("k_from_blocked");
+   return 0;
+}
+
+extern "C" int mfem_amd_domain_lf_3d(int D1D, int Q1D, int64_t ne, const double *B,
+                                     const double *F, double *yE, void *stream)
+{
+   if (ne == 0) { return 0; }
+   MFA_REQUIRE(ne > 0 && ne < 2147483647 && F && yE, "domain_lf_3d: bad arguments");
+   BasisT<MAX_DQ> bg;
+   if (int rc = fill_basis_dyn(bg, D1D, Q1D, B, nullptr)) { return rc; }
+   const size_t lds = sizeof(double)*(size_t)(Q1D*D1D + Q1D*Q1D*Q1D + D1D*Q1D*Q1D + D1D*D1D*Q1D);
+   if (int rc = set_lds(k_domain_lf, lds)) { return rc; }
+   k_domain_lf<<<dim3((unsigned)ne), dim3(256), lds, as_stream(stream)>>>(D1D, Q1D, bg, F, yE);
+   MFA_CHECK_LAUNCH("k_domain_lf");
    return 0;
 }
 

@@ -1,0 +1,759 @@
+// fem.cpp -- H1 hexahedral finite element space with MFEM's dof numbering, the element
+// restriction, grid functions, linear/bilinear forms with partial assembly, and the fused
+// fast paths of ConstrainedOperator and CGSolver on the C ABI.
+#include "mfem.hpp"
+#include <iomanip>
+
+namespace mfem
+{
+
+// ---- FiniteElement: tensor Lagrange element on Gauss-Lobatto points ----------------------
+FiniteElement::FiniteElement(int p, int dim_) : order(p), dim(dim_)
+{
+   MFEM_VERIFY(dim == 3, "mfem_amd: only 3D (hexahedral) elements");
+   MFEM_VERIFY(p >= 1, "H1 elements require order >= 1");
+   const int p1 = p + 1;
+   nodes1d.resize(p1);
+   { std::vector<real_t> w(p1); GaussLobattoPoints(p1, nodes1d.data(), w.data()); }
+   // lexicographic (i,j,k) -> native index: vertices, edges, faces, interior
+   // (fem/fe/fe_base.cpp:2482-2605)
+   dof_map.SetSize(p1*p1*p1);
+   auto L = [p1](int i, int j, int k) { return i + (j + k*p1)*p1; };
+   const int V[8][3] = { {0,0,0},{p,0,0},{p,p,0},{0,p,0},{0,0,p},{p,0,p},{p,p,p},{0,p,p} };
+   int o = 0;
+   for (int v = 0; v < 8; v++) { dof_map[L(V[v][0], V[v][1], V[v][2])] = o++; }
+   // an edge runs from its first to its second vertex (Constants<CUBE>::Edges)
+   const int E[12][2] = { {0,1},{1,2},{3,2},{0,3},{4,5},{5,6},{7,6},{4,7},{0,4},{1,5},{2,6},{3,7} };
+   for (int e = 0; e < 12; e++)
+   {
+      const int *a = V[E[e][0]], *b = V[E[e][1]];
+      for (int i = 1; i < p; i++)
+      { dof_map[L(a[0] + (b[0] - a[0])/p*i, a[1] + (b[1] - a[1])/p*i, a[2] + (b[2] - a[2])/p*i)] = o++; }
+   }
+   // a face is parametrised by (i along v0->v1, j along v0->v3) of its vertex list
+   const int F[6][4] = { {3,2,1,0},{0,1,5,4},{1,2,6,5},{2,3,7,6},{3,0,4,7},{4,5,6,7} };
+   for (int f = 0; f < 6; f++)
+   {
+      const int *a = V[F[f][0]], *b = V[F[f][1]], *c = V[F[f][3]];
+      for (int j = 1; j < p; j++)
+         for (int i = 1; i < p; i++)
+         {
+            dof_map[L(a[0] + (b[0] - a[0])/p*i + (c[0] - a[0])/p*j,
+                      a[1] + (b[1] - a[1])/p*i + (c[1] - a[1])/p*j,
+                      a[2] + (b[2] - a[2])/p*i + (c[2] - a[2])/p*j)] = o++;
+         }
+   }
+   for (int k = 1; k < p; k++) for (int j = 1; j < p; j++) for (int i = 1; i < p; i++) { dof_map[L(i, j, k)] = o++; }
+   MFEM_VERIFY(o == p1*p1*p1, "internal error in the dof map");
+}
+FiniteElement::~FiniteElement() { for (auto &pr : d2q) { delete pr.second; } }
+
+// fem/fe/fe_base.cpp:2622-2673
+const DofToQuad &FiniteElement::GetDofToQuad(const IntegrationRule &ir, DofToQuad::Mode mode) const
+{
+   MFEM_VERIFY(mode == DofToQuad::TENSOR, "mfem_amd: only DofToQuad::TENSOR");
+   MFEM_VERIFY(ir.n1d > 0, "mfem_amd: the integration rule is not a tensor rule");
+   for (auto &pr : d2q) { if (pr.first == &ir) { return *pr.second; } }
+   DofToQuad *m = new DofToQuad;
+   const int D = order + 1, Q = ir.n1d;
+   m->ndof = D; m->nqpt = Q;
+   m->B.SetSize(Q*D); m->G.SetSize(Q*D); m->Bt.SetSize(Q*D); m->Gt.SetSize(Q*D);
+   LagrangeBasisTables(order, nodes1d.data(), Q, ir.x1d.data(), m->B.HostWrite(), m->G.HostWrite());
+   for (int q = 0; q < Q; q++) for (int d = 0; d < D; d++) { m->Bt[d + D*q] = m->B[q + Q*d]; m->Gt[d + D*q] = m->G[q + Q*d]; }
+   d2q.emplace_back(&ir, m);
+   return *m;
+}
+
+// ---- collections ------------------------------------------------------------------------
+H1_FECollection::H1_FECollection(const int p_, const int dim_, const int btype) : p(p_), dim(dim_)
+{
+   MFEM_VERIFY(p >= 1, "H1_FECollection requires order >= 1.");
+   MFEM_VERIFY(dim == 3, "mfem_amd: H1_FECollection is built for dim = 3 only");
+   MFEM_VERIFY(btype == BasisType::GaussLobatto, "mfem_amd: only the Gauss-Lobatto nodal basis");
+   snprintf(h1_name, 32, "H1_%dD_P%d", dim, p);
+   hex = new FiniteElement(p, dim);
+   const int pm1 = p - 1, pm2 = p - 2;
+   // fem/fe_coll.cpp:1788-1794, 1891-1905
+   seg_ord[0].resize(pm1); seg_ord[1].resize(pm1);
+   for (int i = 0; i < pm1; i++) { seg_ord[0][i] = i; seg_ord[1][i] = pm2 - i; }
+   for (int k = 0; k < 8; k++) { quad_ord[k].resize(pm1*pm1); }
+   for (int j = 0; j < pm1; j++)
+      for (int i = 0; i < pm1; i++)
+      {
+         const int o = i + j*pm1;
+         quad_ord[0][o] = i + j*pm1;                   // (0,1,2,3)
+         quad_ord[1][o] = j + i*pm1;                   // (0,3,2,1)
+         quad_ord[2][o] = j + (pm2 - i)*pm1;           // (1,2,3,0)
+         quad_ord[3][o] = (pm2 - i) + j*pm1;           // (1,0,3,2)
+         quad_ord[4][o] = (pm2 - i) + (pm2 - j)*pm1;   // (2,3,0,1)
+         quad_ord[5][o] = (pm2 - j) + (pm2 - i)*pm1;   // (2,1,0,3)
+         quad_ord[6][o] = (pm2 - j) + i*pm1;           // (3,0,1,2)
+         quad_ord[7][o] = i + (pm2 - j)*pm1;           // (3,2,1,0)
+      }
+}
+// fem/fe_coll.cpp:124-: names this path can represent
+FiniteElementCollection *FiniteElementCollection::New(const char *name)
+{
+   int d = 0, p = 0;
+   if (sscanf(name, "H1_%dD_P%d", &d, &p) == 2) { return new H1_FECollection(p, d); }
+   // legacy names: identical dof layout on hexahedra for orders 1 and 2 (vertex / edge-midpoint /
+   // face-centre / centre nodes are orientation-free and the points coincide with Gauss-Lobatto)
+   if (!strcmp(name, "Linear")) { return new H1_FECollection(1, 3); }
+   if (!strcmp(name, "Quadratic")) { return new H1_FECollection(2, 3); }
+   MFEM_ABORT("mfem_amd: finite element collection '" << name << "' is not built (H1_3D_P<k>, Linear, Quadratic)");
+}
+
+// ---- FiniteElementSpace -----------------------------------------------------------------
+FiniteElementSpace::FiniteElementSpace(Mesh *m, const FiniteElementCollection *f, int vd, int ord)
+   : mesh(m), fec(f), h1(dynamic_cast<const H1_FECollection*>(f)), vdim(vd), ordering((Ordering::Type)ord)
+{
+   MFEM_VERIFY(h1, "mfem_amd: only H1_FECollection spaces");
+   MFEM_VERIFY(vdim >= 1, "invalid vdim");
+   Construct();
+}
+void FiniteElementSpace::Update()
+{
+   delete R_lex; R_lex = nullptr;
+   Construct();
+}
+// fem/fespace.cpp:3392-3500 on a conforming hexahedral mesh
+void FiniteElementSpace::Construct()
+{
+   const int p = fec->GetOrder(), ne1 = p - 1, nf1 = ne1*ne1, nb1 = nf1*ne1;
+   const int NE = mesh->GetNE(), nd = (p + 1)*(p + 1)*(p + 1);
+   const int64_t total = (int64_t)mesh->GetNV() + (int64_t)mesh->GetNEdges()*ne1 + (int64_t)mesh->GetNFaces()*nf1 + (int64_t)NE*nb1;
+   MFEM_VERIFY(total*vdim < 2147483647LL && (int64_t)NE*nd < 2147483647LL,
+               "mfem_amd: the space exceeds 32-bit dof indices; partition it over more ranks");
+   nvdofs = mesh->GetNV(); nedofs = mesh->GetNEdges()*ne1; nfdofs = mesh->GetNFaces()*nf1; nbdofs = NE*nb1;
+   ndofs = nvdofs + nedofs + nfdofs + nbdofs;
+   elem_dof.resize((size_t)NE*nd);
+   static const int hex_edges[12][2] = { {0,1},{1,2},{3,2},{0,3},{4,5},{5,6},{7,6},{4,7},{0,4},{1,5},{2,6},{3,7} };
+   for (int e = 0; e < NE; e++)
+   {
+      int *dofs = &elem_dof[(size_t)e*nd];
+      const int *v = mesh->GetElementVertices(e);
+      int o = 0;
+      for (int i = 0; i < 8; i++) { dofs[o++] = v[i]; }
+      if (ne1)
+      {
+         const int *E = mesh->GetElementEdges(e);
+         for (int i = 0; i < 12; i++)
+         {
+            const int ori = (v[hex_edges[i][0]] < v[hex_edges[i][1]]) ? 1 : -1;     // mesh.cpp:7835-7855
+            const int *ind = h1->SegDofOrder(ori);
+            for (int j = 0; j < ne1; j++) { dofs[o++] = nvdofs + E[i]*ne1 + ind[j]; }
+         }
+         const int *F = mesh->GetElementFaces(e);
+         for (int i = 0; i < 6; i++)
+         {
+            const int *ind = h1->QuadDofOrder(mesh->GetElementFaceOrientation(e, i));
+            for (int j = 0; j < nf1; j++) { dofs[o++] = nvdofs + nedofs + F[i]*nf1 + ind[j]; }
+         }
+         const int bbase = nvdofs + nedofs + nfdofs + e*nb1;
+         for (int j = 0; j < nb1; j++) { dofs[o++] = bbase + j; }
+      }
+   }
+   sequence++;
+}
+void FiniteElementSpace::GetElementDofs(int e, Array<int> &dofs) const
+{
+   const int nd = GetTypicalFE()->GetDof();
+   dofs.SetSize(nd);
+   std::copy(ElementDofs(e), ElementDofs(e) + nd, dofs.HostWrite());
+}
+// fem/fespace.cpp:3509-: vertices, edges (oriented), the face (oriented w.r.t. its base)
+void FiniteElementSpace::GetBdrElementDofs(int b, Array<int> &dofs) const
+{
+   const int p = fec->GetOrder(), ne1 = p - 1, nf1 = ne1*ne1;
+   static const int quad_edges[4][2] = { {0,1},{1,2},{2,3},{3,0} };
+   const int *v = mesh->GetBdrElementVertices(b);
+   dofs.SetSize(4 + 4*ne1 + nf1);
+   int o = 0;
+   for (int i = 0; i < 4; i++) { dofs[o++] = v[i]; }
+   if (ne1)
+   {
+      const int *E = mesh->GetBdrElementEdges(b);
+      for (int i = 0; i < 4; i++)
+      {
+         const int *ind = h1->SegDofOrder((v[quad_edges[i][0]] < v[quad_edges[i][1]]) ? 1 : -1);
+         for (int j = 0; j < ne1; j++) { dofs[o++] = nvdofs + E[i]*ne1 + ind[j]; }
+      }
+      const int f = mesh->GetBdrElementFaceIndex(b);
+      const int *ind = h1->QuadDofOrder(Mesh::GetQuadOrientation(mesh->GetFaceVertices(f), v));
+      for (int j = 0; j < nf1; j++) { dofs[o++] = nvdofs + nedofs + f*nf1 + ind[j]; }
+   }
+}
+// fem/fespace.cpp:554-670
+void FiniteElementSpace::GetEssentialVDofs(const Array<int> &bdr_attr_is_ess, Array<int> &ess_vdofs, int component) const
+{
+   ess_vdofs.SetSize(GetVSize());
+   ess_vdofs = 0;
+   Array<int> dofs;
+   for (int b = 0; b < mesh->GetNBE(); b++)
+   {
+      const int attr = mesh->GetBdrAttribute(b);
+      MFEM_VERIFY(attr >= 1 && attr <= bdr_attr_is_ess.Size(), "boundary attribute " << attr << " is out of the marker's range");
+      if (!bdr_attr_is_ess[attr - 1]) { continue; }
+      GetBdrElementDofs(b, dofs);
+      for (int i = 0; i < dofs.Size(); i++)
+      {
+         if (component < 0) { for (int c = 0; c < vdim; c++) { ess_vdofs[DofToVDof(dofs[i], c)] = -1; } }
+         else { ess_vdofs[DofToVDof(dofs[i], component)] = -1; }
+      }
+   }
+}
+void FiniteElementSpace::MarkerToList(const Array<int> &marker, Array<int> &list)
+{
+   int n = 0;
+   for (int i = 0; i < marker.Size(); i++) { if (marker[i]) { n++; } }
+   list.SetSize(n);
+   int *l = list.HostWrite(); const int *m = marker.HostRead();
+   for (int i = 0, k = 0; i < marker.Size(); i++) { if (m[i]) { l[k++] = i; } }
+}
+void FiniteElementSpace::GetEssentialTrueDofs(const Array<int> &bdr_attr_is_ess, Array<int> &ess_tdof_list, int component) const
+{
+   Array<int> ess_vdofs;
+   GetEssentialVDofs(bdr_attr_is_ess, ess_vdofs, component);
+   MarkerToList(ess_vdofs, ess_tdof_list);
+}
+void FiniteElementSpace::GetBoundaryTrueDofs(Array<int> &boundary_dofs, int component) const
+{
+   if (mesh->bdr_attributes.Size())
+   {
+      Array<int> ess_bdr(mesh->bdr_attributes.Max());
+      ess_bdr = 1;
+      GetEssentialTrueDofs(ess_bdr, boundary_dofs, component);
+   }
+   else { boundary_dofs.DeleteAll(); }
+}
+const ElementRestriction *FiniteElementSpace::GetElementRestriction(ElementDofOrdering e_ordering) const
+{
+   MFEM_VERIFY(e_ordering == ElementDofOrdering::LEXICOGRAPHIC, "mfem_amd: only the lexicographic element restriction");
+   if (!R_lex) { R_lex = new ElementRestriction(*this, e_ordering); }
+   return R_lex;
+}
+
+// ---- ElementRestriction (fem/restriction.cpp:26-107 constructor) ------------------------
+ElementRestriction::ElementRestriction(const FiniteElementSpace &f, ElementDofOrdering)
+   : fes(f), ne(f.GetNE()), vdim(f.GetVDim()), ndofs(f.GetNDofs()), dof(f.GetTypicalFE()->GetDof()),
+     byvdim(f.GetOrdering() == Ordering::byVDIM)
+{
+   height = vdim*ne*dof; width = f.GetVSize();
+   const int *dof_map = f.GetTypicalFE()->GetDofMap().HostRead();
+   offsets.SetSize(ndofs + 1); indices.SetSize(ne*dof); gather_map.SetSize(ne*dof);
+   int *off = offsets.HostWrite(), *ind = indices.HostWrite(), *gm = gather_map.HostWrite();
+   for (int i = 0; i <= ndofs; ++i) { off[i] = 0; }
+   for (int e = 0; e < ne; ++e)
+   {
+      const int *ed = f.ElementDofs(e);
+      for (int d = 0; d < dof; ++d) { ++off[ed[d] + 1]; }
+   }
+   for (int i = 1; i <= ndofs; ++i) { off[i] += off[i - 1]; }
+   // element-major, lexicographic local order: contributions to an L-dof end up sorted by
+   // element, then by local index (the order the transpose sums them in)
+   for (int e = 0; e < ne; ++e)
+   {
+      const int *ed = f.ElementDofs(e);
+      for (int d = 0; d < dof; ++d)
+      {
+         const int gid = ed[dof_map[d]], lid = dof*e + d;
+         gm[lid] = gid;
+         ind[off[gid]++] = lid;
+      }
+   }
+   for (int i = ndofs; i > 0; --i) { off[i] = off[i - 1]; }
+   off[0] = 0;
+}
+void ElementRestriction::Mult(const Vector &x, Vector &y) const
+{
+   MFEM_VERIFY(x.Size() == Width(), "ElementRestriction::Mult: wrong input size");
+   y.SetSize(Height());
+   if (vdim == 1) { MFEM_AMD_CALL(mfem_amd_restrict_gather((int64_t)ne*dof, gather_map.Read(), x.Read(), y.Write(), nullptr)); }
+   else
+   {
+      MFEM_AMD_CALL(mfem_amd_restrict_gather_vdim((int64_t)ne*dof, dof, vdim, byvdim ? 1 : 0, ndofs,
+                                                  gather_map.Read(), x.Read(), y.Write(), nullptr));
+   }
+}
+void ElementRestriction::MultTranspose(const Vector &x, Vector &y) const
+{
+   MFEM_VERIFY(vdim == 1, "mfem_amd: the transpose restriction is built for scalar spaces");
+   MFEM_VERIFY(x.Size() == Height(), "ElementRestriction::MultTranspose: wrong input size");
+   y.SetSize(Width());
+   MFEM_AMD_CALL(mfem_amd_restrict_scatter(ndofs, offsets.Read(), indices.Read(), x.Read(), y.Write(), 0, 0, nullptr));
+}
+void ElementRestriction::AddMultTranspose(const Vector &x, Vector &y, const real_t a) const
+{
+   MFEM_VERIFY(vdim == 1 && a == 1.0, "mfem_amd: AddMultTranspose is built for scalar spaces and a = 1");
+   MFEM_AMD_CALL(mfem_amd_restrict_scatter(ndofs, offsets.Read(), indices.Read(), x.Read(), y.ReadWrite(), 1, 0, nullptr));
+}
+void ElementRestriction::AbsMultTranspose(const Vector &x, Vector &y) const
+{
+   MFEM_VERIFY(vdim == 1, "mfem_amd: the transpose restriction is built for scalar spaces");
+   y.SetSize(Width());
+   MFEM_AMD_CALL(mfem_amd_restrict_scatter(ndofs, offsets.Read(), indices.Read(), x.Read(), y.Write(), 0, 1, nullptr));
+}
+
+// ---- GridFunction -----------------------------------------------------------------------
+GridFunction::~GridFunction()
+{
+   if (own_fes) { delete fes; delete fec_owned; }
+}
+void GridFunction::GetNodeCoordinates(std::vector<real_t> &xyz) const
+{
+   MFEM_VERIFY(fes->GetVDim() == 1, "scalar spaces only");
+   const Mesh &mesh = *fes->GetMesh();
+   std::vector<real_t> xe;
+   const int Dn = internal::ElementNodesLex(mesh, xe);
+   std::vector<real_t> gn(Dn), w(Dn);
+   GaussLobattoPoints(Dn, gn.data(), w.data());
+   const FiniteElement *fe = fes->GetTypicalFE();
+   const int D = fe->GetOrder() + 1, nd = D*D*D, ndn = Dn*Dn*Dn;
+   const std::vector<real_t> P = internal::InterpMatrix(gn, fe->Nodes1D());
+   std::vector<real_t> loc((size_t)3*nd);
+   xyz.assign((size_t)3*fes->GetNDofs(), 0.0);
+   const int *dmap = fe->GetDofMap().HostRead();
+   for (int e = 0; e < fes->GetNE(); e++)
+   {
+      internal::TensorInterp3(Dn, D, P.data(), P.data(), P.data(), &xe[(size_t)3*ndn*e], loc.data());
+      const int *dofs = fes->ElementDofs(e);
+      for (int l = 0; l < nd; l++) for (int c = 0; c < 3; c++) { xyz[(size_t)3*dofs[dmap[l]] + c] = loc[l + nd*c]; }
+   }
+}
+void GridFunction::ProjectCoefficient(Coefficient &coeff)
+{
+   std::vector<real_t> xyz;
+   GetNodeCoordinates(xyz);
+   Vector pt(3);
+   real_t *v = HostWrite();
+   for (int i = 0; i < fes->GetNDofs(); i++)
+   {
+      for (int c = 0; c < 3; c++) { pt(c) = xyz[(size_t)3*i + c]; }
+      v[i] = coeff.EvalAt(pt);
+   }
+}
+real_t GridFunction::ComputeMaxError(Coefficient &exsol) const
+{
+   std::vector<real_t> xyz;
+   GetNodeCoordinates(xyz);
+   Vector pt(3);
+   const real_t *v = HostRead();
+   real_t m = 0.0;
+   for (int i = 0; i < fes->GetNDofs(); i++)
+   {
+      for (int c = 0; c < 3; c++) { pt(c) = xyz[(size_t)3*i + c]; }
+      m = std::max(m, std::fabs(v[i] - exsol.EvalAt(pt)));
+   }
+   return m;
+}
+// fem/gridfunc.cpp Save: space header, then the values
+void GridFunction::Save(std::ostream &os) const
+{
+   os << "FiniteElementSpace\nFiniteElementCollection: " << fes->FEColl()->Name() << "\nVDim: " << fes->GetVDim()
+      << "\nOrdering: " << (int)fes->GetOrdering() << "\n\n";
+   const real_t *v = HostRead();
+   const int vd = fes->GetVDim(), nd = fes->GetNDofs();
+   if (vd == 1) { for (int i = 0; i < nd; i++) { os << v[i] << '\n'; } }
+   else if (fes->GetOrdering() == Ordering::byNODES)
+   { for (int i = 0; i < nd; i++) { for (int c = 0; c < vd; c++) { os << v[i + c*nd] << (c + 1 < vd ? ' ' : '\n'); } } }
+   else { for (int i = 0; i < nd; i++) { for (int c = 0; c < vd; c++) { os << v[i*vd + c] << (c + 1 < vd ? ' ' : '\n'); } } }
+   os.flush();
+}
+std::ostream &operator<<(std::ostream &os, const GridFunction &gf) { gf.Save(os); return os; }
+
+// ---- geometry and coefficients at the quadrature points ----------------------------------
+namespace
+{
+struct NodesAtRule
+{
+   int Dn = 0;
+   std::vector<real_t> Bn, Gn;     // nodal basis at the rule's 1D points (HOST tables of the C ABI)
+   Vector nodesE;                  // (Dn^3, 3, NE)
+};
+// GeometricFactors::Compute's first half (mesh/mesh.cpp:15178-15231): nodes -> E-nodes
+void prepare_nodes(Mesh &mesh, const IntegrationRule &ir, NodesAtRule &g)
+{
+   mesh.EnsureNodes();
+   const GridFunction *nodes = mesh.GetNodes();
+   const FiniteElementSpace *nfes = nodes->FESpace();
+   const DofToQuad &nm = nfes->GetTypicalFE()->GetDofToQuad(ir, DofToQuad::TENSOR);
+   g.Dn = nm.ndof;
+   g.Bn.assign(nm.B.HostRead(), nm.B.HostRead() + nm.B.Size());
+   g.Gn.assign(nm.G.HostRead(), nm.G.HostRead() + nm.G.Size());
+   nfes->GetElementRestriction(ElementDofOrdering::LEXICOGRAPHIC)->Mult(*nodes, g.nodesE);
+}
+// CoefficientVector::Project (fem/coefficient.cpp:1985-2051): a constant stays one number,
+// anything else is evaluated at the physical quadrature points, (Q^3, NE).
+void eval_coefficient(Mesh &mesh, const IntegrationRule &ir, Coefficient *Q, Vector &C, int &const_c)
+{
+   real_t cval = 1.0;
+   if (!Q || Q->IsConstant(cval))
+   {
+      C.SetSize(1); C.HostWrite()[0] = cval; const_c = 1;
+      return;
+   }
+   const_c = 0;
+   std::vector<real_t> xe;
+   const int Dn = internal::ElementNodesLex(mesh, xe);
+   std::vector<real_t> gn(Dn), w(Dn);
+   GaussLobattoPoints(Dn, gn.data(), w.data());
+   const int Q1 = ir.n1d, nq = Q1*Q1*Q1, ndn = Dn*Dn*Dn, NE = mesh.GetNE();
+   const std::vector<real_t> P = internal::InterpMatrix(gn, ir.x1d);
+   std::vector<real_t> loc((size_t)3*nq);
+   C.SetSize(nq*NE);
+   real_t *c = C.HostWrite();
+   Vector pt(3);
+   for (int e = 0; e < NE; e++)
+   {
+      internal::TensorInterp3(Dn, Q1, P.data(), P.data(), P.data(), &xe[(size_t)3*ndn*e], loc.data());
+      for (int q = 0; q < nq; q++)
+      {
+         for (int k = 0; k < 3; k++) { pt(k) = loc[q + nq*k]; }
+         c[(size_t)nq*e + q] = Q->EvalAt(pt);
+      }
+   }
+}
+}
+
+// ---- LinearForm (fem/linearform.cpp Assemble; device kernel of lininteg_domain.cpp:22-59) --
+void LinearForm::Assemble()
+{
+   MFEM_VERIFY(fes->GetVDim() == 1, "mfem_amd: scalar linear forms only");
+   Vector::operator=(0.0);
+   const FiniteElement *fe = fes->GetTypicalFE();
+   const ElementRestriction *R = fes->GetElementRestriction(ElementDofOrdering::LEXICOGRAPHIC);
+   const int NE = fes->GetNE();
+   Vector bE(R->Height());
+   for (LinearFormIntegrator *lfi : domain_integs)
+   {
+      DomainLFIntegrator *dlf = dynamic_cast<DomainLFIntegrator*>(lfi);
+      MFEM_VERIFY(dlf, "mfem_amd: only DomainLFIntegrator");
+      const IntegrationRule &ir = dlf->IntRule ? *dlf->IntRule : IntRules.Get(Geometry::CUBE, dlf->oa*fe->GetOrder() + dlf->ob);
+      const DofToQuad &maps = fe->GetDofToQuad(ir, DofToQuad::TENSOR);
+      NodesAtRule g; prepare_nodes(*fes->GetMesh(), ir, g);
+      Vector C; int const_c;
+      eval_coefficient(*fes->GetMesh(), ir, &dlf->Q, C, const_c);
+      const int Q1 = maps.nqpt;
+      Vector F(Q1*Q1*Q1*NE);       // W * f * detJ at the points = a mass setup with coefficient f
+      MFEM_AMD_CALL(mfem_amd_pa_setup_from_nodes_3d(0, g.Dn, Q1, 1, NE, g.Bn.data(), g.Gn.data(), ir.GetWeights().Read(),
+                                                    g.nodesE.Read(), C.Read(), const_c, 0, F.Write(), nullptr, nullptr));
+      bE = 0.0;
+      MFEM_AMD_CALL(mfem_amd_domain_lf_3d(maps.ndof, Q1, NE, maps.B.HostRead(), F.Read(), bE.ReadWrite(), nullptr));
+      R->AddMultTranspose(bE, *this);
+   }
+}
+
+// ---- integrators ------------------------------------------------------------------------
+// fem/bilininteg.cpp (DiffusionIntegrator::GetRule): tensor elements use order 2p + dim - 1
+const IntegrationRule &DiffusionIntegrator::GetRule(const FiniteElement &trial_fe, const FiniteElement &test_fe)
+{
+   const int order = trial_fe.GetOrder() + test_fe.GetOrder() + trial_fe.GetDim() - 1;
+   return IntRules.Get(Geometry::CUBE, order);
+}
+// fem/bilininteg.cpp:1450-1462: 2p + OrderW, OrderW = dim*order_nodes - 1 for tensor nodes
+const IntegrationRule &MassIntegrator::GetRule(const FiniteElement &trial_fe, const FiniteElement &test_fe, int nodes_order)
+{
+   const int order = trial_fe.GetOrder() + test_fe.GetOrder() + (trial_fe.GetDim()*nodes_order - 1);
+   return IntRules.Get(Geometry::CUBE, order);
+}
+
+// AssemblePA (fem/integ/bilininteg_diffusion_pa.cpp:89-147, bilininteg_mass_pa.cpp:24-79) with
+// the geometric factors fused in: nodes -> pa_data in one kernel, J is never stored.
+void BilinearFormIntegrator::SetupPA(const FiniteElementSpace &fes, int kind_, Coefficient *Q, const IntegrationRule &ir)
+{
+   MFEM_VERIFY(fes.GetVDim() == 1, "mfem_amd: scalar spaces only");
+   Mesh *mesh = fes.GetMesh();
+   const FiniteElement *fe = fes.GetTypicalFE();
+   kind = kind_; ne = fes.GetNE();
+   maps = &fe->GetDofToQuad(ir, DofToQuad::TENSOR);
+   dofs1D = maps->ndof; quad1D = maps->nqpt;
+   // the blocked HBM layout needs a specialised (D1D,Q1D) kernel; otherwise keep MFEM's layout
+   pa_layout = mfem_amd_has_specialization(kind, dofs1D, quad1D) ? 1 : 0;
+   pa_data_mfem.Destroy();
+   NodesAtRule g; prepare_nodes(*mesh, ir, g);
+   Vector C; int const_c;
+   eval_coefficient(*mesh, ir, Q, C, const_c);
+   pa_data.SetSize((int)mfem_amd_pa_data_size(kind, pa_layout, quad1D, ne));
+   if (pa_layout) { pa_data.Write(); pa_data = 0.0; }     // padding of the last batch must be finite
+   MFEM_AMD_CALL(mfem_amd_pa_setup_from_nodes_3d(kind, g.Dn, quad1D, 1, ne, g.Bn.data(), g.Gn.data(), ir.GetWeights().Read(),
+                                                 g.nodesE.Read(), C.Read(), const_c, pa_layout,
+                                                 pa_layout ? pa_data.ReadWrite() : pa_data.Write(), nullptr, nullptr));
+}
+const Vector &BilinearFormIntegrator::MFEMLayoutData() const
+{
+   if (pa_layout == 0) { return pa_data; }
+   if (pa_data_mfem.Size() == 0)
+   {
+      pa_data_mfem.SetSize((int)mfem_amd_pa_data_size(kind, 0, quad1D, ne));
+      MFEM_AMD_CALL(mfem_amd_pa_data_from_blocked(kind, quad1D, ne, pa_data.Read(), pa_data_mfem.Write(), nullptr));
+   }
+   return pa_data_mfem;
+}
+void DiffusionIntegrator::AssemblePA(const FiniteElementSpace &fes)
+{
+   const FiniteElement &el = *fes.GetTypicalFE();
+   SetupPA(fes, 1, Q, IntRule ? *IntRule : GetRule(el, el));
+}
+void DiffusionIntegrator::AddMultPA(const Vector &x, Vector &y) const
+{
+   MFEM_VERIFY(maps, "AssemblePA must be called first");
+   MFEM_AMD_CALL(mfem_amd_pa_diffusion_apply_3d(dofs1D, quad1D, ne, 1, maps->B.HostRead(), maps->G.HostRead(),
+                                                MFEMLayoutData().Read(), x.Read(), y.ReadWrite(), nullptr));
+}
+void DiffusionIntegrator::AssembleDiagonalPA(Vector &diag)
+{
+   MFEM_VERIFY(maps, "AssemblePA must be called first");
+   MFEM_AMD_CALL(mfem_amd_pa_diffusion_diag_3d(dofs1D, quad1D, ne, 1, maps->B.HostRead(), maps->G.HostRead(),
+                                               pa_data.Read(), pa_layout, diag.ReadWrite(), nullptr));
+}
+void MassIntegrator::AssemblePA(const FiniteElementSpace &fes)
+{
+   const FiniteElement &el = *fes.GetTypicalFE();
+   fes.GetMesh()->EnsureNodes();
+   const int nodes_order = fes.GetMesh()->GetNodalFESpace()->GetMaxElementOrder();
+   SetupPA(fes, 0, Q, IntRule ? *IntRule : GetRule(el, el, nodes_order));
+}
+void MassIntegrator::AddMultPA(const Vector &x, Vector &y) const
+{
+   MFEM_VERIFY(maps, "AssemblePA must be called first");
+   MFEM_AMD_CALL(mfem_amd_pa_mass_apply_3d(dofs1D, quad1D, ne, maps->B.HostRead(), MFEMLayoutData().Read(),
+                                           x.Read(), y.ReadWrite(), nullptr));
+}
+void MassIntegrator::AssembleDiagonalPA(Vector &diag)
+{
+   MFEM_VERIFY(maps, "AssemblePA must be called first");
+   MFEM_AMD_CALL(mfem_amd_pa_mass_diag_3d(dofs1D, quad1D, ne, maps->B.HostRead(), pa_data.Read(), pa_layout,
+                                          diag.ReadWrite(), nullptr));
+}
+
+// ---- PABilinearFormExtension (fem/bilinearform_ext.cpp:256-564) -------------------------
+PABilinearFormExtension::PABilinearFormExtension(BilinearForm *form)
+   : Operator(form->FESpace()->GetVSize()), a(form), fes(form->FESpace()) {}
+void PABilinearFormExtension::Assemble()
+{
+   elem_restrict = fes->GetElementRestriction(ElementDofOrdering::LEXICOGRAPHIC);
+   localY.SetSize(elem_restrict->Height());
+   MFEM_VERIFY(!a->domain_integs.empty(), "the form has no domain integrators");
+   for (BilinearFormIntegrator *bfi : a->domain_integs) { bfi->AssemblePA(*fes); }
+}
+const BilinearFormIntegrator *PABilinearFormExtension::SingleIntegrator() const
+{
+   return (a->domain_integs.size() == 1 && a->domain_integs[0]->maps) ? a->domain_integs[0] : nullptr;
+}
+void PABilinearFormExtension::Mult(const Vector &x, Vector &y) const
+{
+   MFEM_VERIFY(elem_restrict, "BilinearForm::Assemble must be called first");
+   MFEM_VERIFY(x.Size() == Width() && y.Size() == Height(), "incompatible sizes");
+   if (const BilinearFormIntegrator *bfi = SingleIntegrator())
+   {
+      // gather fused into the element kernel: no localX, no memset of localY
+      MFEM_AMD_CALL(mfem_amd_pa_apply_L2E(bfi->kind, bfi->pa_layout, bfi->dofs1D, bfi->quad1D, bfi->ne,
+                                          bfi->maps->B.HostRead(), bfi->maps->G.HostRead(), bfi->pa_data.Read(),
+                                          elem_restrict->GatherMap().Read(), x.Read(), localY.Write(), nullptr));
+   }
+   else
+   {
+      elem_restrict->Mult(x, localX);
+      localY = 0.0;
+      for (BilinearFormIntegrator *bfi : a->domain_integs) { bfi->AddMultPA(localX, localY); }
+   }
+   elem_restrict->MultTranspose(localY, y);
+}
+void PABilinearFormExtension::AssembleDiagonal(Vector &diag) const
+{
+   MFEM_VERIFY(elem_restrict, "BilinearForm::Assemble must be called first");
+   diag.SetSize(Height());
+   localY = 0.0;
+   for (BilinearFormIntegrator *bfi : a->domain_integs) { bfi->AssembleDiagonalPA(localY); }
+   elem_restrict->AbsMultTranspose(localY, diag);       // bilinearform_ext.cpp:413-418
+}
+
+// ---- BilinearForm -----------------------------------------------------------------------
+BilinearForm::~BilinearForm()
+{
+   delete ext;
+   for (auto *i : domain_integs) { delete i; }
+}
+void BilinearForm::SetAssemblyLevel(AssemblyLevel assembly_level)
+{
+   MFEM_VERIFY(!ext, "the assembly level has already been set!");       // bilinearform.cpp:111-114
+   assembly = assembly_level;
+   if (assembly == AssemblyLevel::PARTIAL) { ext = new PABilinearFormExtension(this); }
+   else if (assembly != AssemblyLevel::LEGACY)
+   { MFEM_ABORT("mfem_amd: only AssemblyLevel::PARTIAL is built (the partial-assembly path)"); }
+}
+void BilinearForm::Assemble(int)
+{
+   if (!ext) { MFEM_ABORT("mfem_amd: only AssemblyLevel::PARTIAL is built: call SetAssemblyLevel(AssemblyLevel::PARTIAL) (ex1: -pa)"); }
+   ext->Assemble();
+}
+void BilinearForm::Mult(const Vector &x, Vector &y) const
+{
+   MFEM_VERIFY(ext, "mfem_amd: BilinearForm::Mult needs AssemblyLevel::PARTIAL");
+   ext->Mult(x, y);
+}
+void BilinearForm::AssembleDiagonal(Vector &diag) const
+{
+   MFEM_VERIFY(ext, "mfem_amd: BilinearForm::AssembleDiagonal needs AssemblyLevel::PARTIAL");
+   ext->AssembleDiagonal(diag);
+}
+// fem/bilinearform_ext.cpp:468-485: A owns the ConstrainedOperator
+void BilinearForm::FormLinearSystem(const Array<int> &ess_tdof_list, Vector &x, Vector &b, OperatorHandle &A,
+                                    Vector &X, Vector &B, int copy_interior)
+{
+   MFEM_VERIFY(ext, "mfem_amd: FormLinearSystem needs AssemblyLevel::PARTIAL");
+   Operator *oper;
+   ext->Operator::FormLinearSystem(ess_tdof_list, x, b, oper, X, B, copy_interior);
+   A.Reset(oper);
+}
+void BilinearForm::FormSystemMatrix(const Array<int> &ess_tdof_list, OperatorHandle &A)
+{
+   MFEM_VERIFY(ext, "mfem_amd: FormSystemMatrix needs AssemblyLevel::PARTIAL");
+   Operator *oper;
+   ext->FormSystemOperator(ess_tdof_list, oper);
+   A.Reset(oper);
+}
+void BilinearForm::RecoverFEMSolution(const Vector &X, const Vector &, Vector &x) { x = X; }
+
+OperatorJacobiSmoother::OperatorJacobiSmoother(const BilinearForm &a, const Array<int> &ess, const real_t dmp)
+   : Solver(a.Height()), damping(dmp), ess_tdof_list(&ess)
+{
+   Vector diag(a.Height());
+   a.AssembleDiagonal(diag);
+   Setup(diag);
+}
+
+// ---- ConstrainedOperator (linalg/operator.cpp:511-646) -----------------------------------
+bool PABilinearFormExtension::FillOperator(mfem_amd_pa_operator &op) const
+{
+   const BilinearFormIntegrator *bfi = SingleIntegrator();
+   if (!bfi || !elem_restrict) { return false; }
+   std::memset(&op, 0, sizeof(op));
+   const ElementRestriction *R = elem_restrict;
+   op.kind = bfi->kind; op.pa_layout = bfi->pa_layout; op.D1D = bfi->dofs1D; op.Q1D = bfi->quad1D;
+   op.ne = bfi->ne; op.ndofs = Height();
+   op.B = bfi->maps->B.HostRead(); op.G = bfi->maps->G.HostRead();
+   op.pa_data = bfi->pa_data.Read();
+   op.gather_map = R->GatherMap().Read(); op.masked_gather_map = op.gather_map;
+   op.offsets = R->Offsets().Read(); op.indices = R->Indices().Read();
+   op.yE = localY.Write();
+   return true;
+}
+
+ConstrainedOperator::ConstrainedOperator(Operator *A_, const Array<int> &list, bool own, DiagonalPolicy dp)
+   : Operator(A_->Height(), A_->Width()), A(A_), own_A(own), diag_policy(dp)
+{
+   MFEM_VERIFY(diag_policy == DIAG_ONE, "mfem_amd: only DiagonalPolicy::DIAG_ONE");
+   list.Copy(constraint_list);
+   z.SetSize(height); w.SetSize(height);
+   const PABilinearFormExtension *ext = dynamic_cast<const PABilinearFormExtension*>(A);
+   if (ext && ext->FillOperator(cop))
+   {
+      pa = ext;
+      // fold `z = x; z[ess] = 0` into the gather and `y[ess] = x[ess]` into the transpose
+      marker.SetSize(height); marker = (unsigned char)0;
+      marker.Read();
+      const int ness = constraint_list.Size();
+      if (ness)
+      {
+         MFEM_AMD_CALL(mfem_amd_set_marker(ness, constraint_list.Read(), marker.ReadWrite(), nullptr));
+         const ElementRestriction *R = ext->GetElementRestriction();
+         masked_gather.SetSize(R->GatherMap().Size());
+         MFEM_AMD_CALL(mfem_amd_mask_gather_map(R->GatherMap().Size(), R->GatherMap().Read(), marker.Read(),
+                                                masked_gather.Write(), nullptr));
+         cop.masked_gather_map = masked_gather.Read();
+      }
+      cop.ness = ness; cop.ess = ness ? constraint_list.Read() : nullptr; cop.ess_marker = marker.Read();
+   }
+}
+void ConstrainedOperator::AssembleDiagonal(Vector &diag) const
+{
+   A->AssembleDiagonal(diag);
+   diag.SetSubVector(constraint_list, 1.0);
+}
+void ConstrainedOperator::EliminateRHS(const Vector &x, Vector &b) const
+{
+   w = 0.0;
+   const int n = constraint_list.Size();
+   if (n) { MFEM_AMD_CALL(mfem_amd_set_subvector(n, constraint_list.Read(), x.Read(), 0.0, w.ReadWrite(), nullptr)); }
+   A->Mult(w, z);
+   b -= z;
+   if (n) { MFEM_AMD_CALL(mfem_amd_set_subvector(n, constraint_list.Read(), x.Read(), 0.0, b.ReadWrite(), nullptr)); }
+}
+void ConstrainedOperator::Mult(const Vector &x, Vector &y) const
+{
+   MFEM_VERIFY(x.Size() == Width() && y.Size() == Height(), "incompatible sizes");
+   if (pa)
+   {
+      MFEM_AMD_CALL(mfem_amd_pa_constrained_mult(&cop, x.Read(), y.Write(), nullptr));
+      return;
+   }
+   const int n = constraint_list.Size();
+   if (n == 0) { A->Mult(x, y); return; }
+   z = x;
+   z.SetSubVector(constraint_list, 0.0);
+   A->Mult(z, y);
+   MFEM_AMD_CALL(mfem_amd_set_subvector(n, constraint_list.Read(), x.Read(), 0.0, y.ReadWrite(), nullptr));
+}
+
+// ---- CGSolver: the fused, device-resident Jacobi-PCG of the C ABI -------------------------
+bool CGSolver::FusedMult(const Vector &b, Vector &x) const
+{
+   mfem_amd_pa_operator op;
+   if (const ConstrainedOperator *co = dynamic_cast<const ConstrainedOperator*>(oper))
+   {
+      if (!co->pa) { return false; }
+      op = co->cop;
+   }
+   else
+   {
+      const PABilinearFormExtension *ext = dynamic_cast<const PABilinearFormExtension*>(oper);
+      if (!ext) { if (const BilinearForm *bf = dynamic_cast<const BilinearForm*>(oper)) { ext = bf->GetPAExtension(); } }
+      if (!ext || !ext->FillOperator(op)) { return false; }
+   }
+   const OperatorJacobiSmoother *jac = nullptr;
+   if (prec) { jac = dynamic_cast<const OperatorJacobiSmoother*>(prec); if (!jac) { return false; } }
+   const int n = width;
+   MFEM_VERIFY(b.Size() == n && x.Size() == n, "incompatible sizes");
+   const int64_t wsb = mfem_amd_pcg_workspace_bytes(n, max_iter);
+   ws.SetSize((int)((wsb + 7)/8));
+   history.assign((size_t)std::max(max_iter, 1) + 2, 0.0);
+   mfem_amd_pcg_result res;
+   const Vector *rhs = &b;
+   if (iterative_mode)
+   {
+      // residual correction: CG's r, d, z recurrences do not involve x, so solving
+      // A e = b - A x0 from e = 0 takes the same iterations; x = x0 + e
+      r.SetSize(n); d.SetSize(n);
+      oper->Mult(x, r);
+      subtract(b, r, r);
+      rhs = &r;
+   }
+   Vector &sol = iterative_mode ? d : x;
+   MFEM_AMD_CALL(mfem_amd_pcg_pa(&op, jac ? jac->dinv.Read() : nullptr, rhs->Read(), sol.Write(), rel_tol, abs_tol,
+                                 max_iter, 8, ws.Write(), &res, history.data(), nullptr));
+   if (iterative_mode) { x += d; }
+   final_iter = res.iterations; converged = res.converged != 0;
+   history.resize((size_t)res.iterations + 1);
+   const real_t nom0 = res.initial_nom, betanom = res.final_nom;
+   initial_norm = nom0 >= 0.0 ? std::sqrt(nom0) : nom0;
+   final_norm = betanom >= 0.0 ? std::sqrt(betanom) : betanom;
+   // the reference's log, printed after the (asynchronous) solve
+   const bool it_print = print_level == 1, summary = print_level == 2, first_last = print_level == 3, warnings = print_level >= 0;
+   if (it_print)
+   { for (size_t i = 0; i < history.size(); i++) { mfem::out << "   Iteration : " << std::setw(3) << i << "  (B r, r) = " << history[i] << '\n'; } }
+   else if (first_last)
+   {
+      mfem::out << "   Iteration : " << std::setw(3) << 0 << "  (B r, r) = " << nom0 << " ...\n";
+      if (final_iter > 0) { mfem::out << "   Iteration : " << std::setw(3) << final_iter << "  (B r, r) = " << betanom << '\n'; }
+   }
+   if (final_iter > 0)
+   {
+      if (summary || (warnings && !converged)) { mfem::out << "PCG: Number of iterations: " << final_iter << '\n'; }
+      if (summary || it_print || first_last) { mfem::out << "Average reduction factor = " << std::pow(betanom/nom0, 0.5/final_iter) << '\n'; }
+      if (warnings && !converged) { mfem::out << "PCG: No convergence!" << '\n'; }
+   }
+   return true;
+}
+
+} // namespace mfem

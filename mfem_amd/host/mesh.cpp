@@ -1,0 +1,726 @@
+// mesh.cpp -- conforming hexahedral meshes with MFEM's conventions: vertex / element /
+// boundary layout of Mesh::Make3D, the generalised Hilbert element ordering, edge and face
+// numbering by first appearance, uniform refinement, high-order nodes, mesh v1.0 I/O.
+// Host-only integer work: every table is checked bit for bit against the reference's in
+// tests/test_host_cxx.py.
+#include "mfem.hpp"
+#include <unordered_map>
+#include <array>
+#include <iomanip>
+
+namespace mfem
+{
+
+// fem/geom.cpp:1020-1036
+static const int hex_edges[12][2] =
+{ {0,1},{1,2},{3,2},{0,3},{4,5},{5,6},{7,6},{4,7},{0,4},{1,5},{2,6},{3,7} };
+static const int hex_faces[6][4] =
+{ {3,2,1,0},{0,1,5,4},{1,2,6,5},{2,3,7,6},{3,0,4,7},{4,5,6,7} };
+static const int quad_edges[4][2] = { {0,1},{1,2},{2,3},{3,0} };
+
+// ---- generalised Hilbert curve over an nx x ny x nz grid -------------------------------
+// (mesh/ncmesh.cpp:5435-5634.)  A box is described by its corner and three signed axis
+// vectors a (major), b, c; it is split recursively so that consecutive cells always share
+// a face.  Restated with small vector helpers.
+namespace
+{
+struct I3 { int x, y, z; };
+inline I3 operator+(I3 a, I3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline I3 operator-(I3 a, I3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline I3 operator-(I3 a) { return {-a.x, -a.y, -a.z}; }
+inline int sgn(int v) { return (v > 0) - (v < 0); }
+inline I3 unit(I3 a) { return {sgn(a.x), sgn(a.y), sgn(a.z)}; }
+inline I3 half(I3 a) { return {a.x/2, a.y/2, a.z/2}; }
+inline int len(I3 a) { return std::abs(a.x + a.y + a.z); }
+
+void hilbert3(I3 o, I3 a, I3 b, I3 c, std::vector<int> &out)
+{
+   const int w = len(a), h = len(b), d = len(c);
+   const I3 da = unit(a), db = unit(b), dc = unit(c);
+   auto line = [&](int n, I3 step)
+   { for (int i = 0; i < n; i++, o = o + step) { out.push_back(o.x); out.push_back(o.y); out.push_back(o.z); } };
+   if (h == 1 && d == 1) { line(w, da); return; }
+   if (w == 1 && d == 1) { line(h, db); return; }
+   if (w == 1 && h == 1) { line(d, dc); return; }
+   I3 a2 = half(a), b2 = half(b), c2 = half(c);
+   // prefer even steps
+   if ((len(a2) & 1) && w > 2) { a2 = a2 + da; }
+   if ((len(b2) & 1) && h > 2) { b2 = b2 + db; }
+   if ((len(c2) & 1) && d > 2) { c2 = c2 + dc; }
+   if (2*w > 3*h && 2*w > 3*d)                 // wide: split along a only
+   {
+      hilbert3(o, a2, b, c, out);
+      hilbert3(o + a2, a - a2, b, c, out);
+   }
+   else if (3*h > 4*d)                          // do not split along c
+   {
+      hilbert3(o, b2, c, a2, out);
+      hilbert3(o + b2, a, b - b2, c, out);
+      hilbert3(o + (a - da) + (b2 - db), -b2, c, -(a - a2), out);
+   }
+   else if (3*d > 4*h)                          // do not split along b
+   {
+      hilbert3(o, c2, a2, b, out);
+      hilbert3(o + c2, a, b, c - c2, out);
+      hilbert3(o + (a - da) + (c2 - dc), -c2, -(a - a2), b, out);
+   }
+   else                                         // regular case: split along all three
+   {
+      hilbert3(o, b2, c2, a2, out);
+      hilbert3(o + b2, c, a2, b - b2, out);
+      hilbert3(o + (b2 - db) + (c - dc), a, -b2, -(c - c2), out);
+      hilbert3(o + (a - da) + b2 + (c - dc), -c, -(a - a2), b - b2, out);
+      hilbert3(o + (a - da) + (b2 - db), -b2, c2, -(a - a2), out);
+   }
+}
+void grid_sfc_ordering_3d(int nx, int ny, int nz, std::vector<int> &coords)
+{
+   coords.clear(); coords.reserve((size_t)3*nx*ny*nz);
+   const I3 X = {nx, 0, 0}, Y = {0, ny, 0}, Z = {0, 0, nz}, O = {0, 0, 0};
+   if (nx >= ny && nx >= nz) { hilbert3(O, X, Y, Z, coords); }
+   else if (ny >= nx && ny >= nz) { hilbert3(O, Y, X, Z, coords); }
+   else { hilbert3(O, Z, X, Y, coords); }
+}
+} // namespace
+
+// ---- construction ----------------------------------------------------------------------
+void Mesh::Destroy()
+{
+   if (own_nodes) { delete Nodes; }
+   Nodes = nullptr; own_nodes = false;
+}
+void Mesh::Swap(Mesh &o)
+{
+   std::swap(Dim, o.Dim); std::swap(spaceDim, o.spaceDim);
+   vertices.swap(o.vertices); elements.swap(o.elements); elem_attr.swap(o.elem_attr);
+   boundary.swap(o.boundary); bdr_attr.swap(o.bdr_attr);
+   std::swap(NumOfEdges, o.NumOfEdges); std::swap(NumOfFaces, o.NumOfFaces);
+   el_to_edge.swap(o.el_to_edge); el_to_face.swap(o.el_to_face); bel_to_edge.swap(o.bel_to_edge);
+   be_to_face.swap(o.be_to_face); face_vertices.swap(o.face_vertices);
+   face_elem1.swap(o.face_elem1); face_elem2.swap(o.face_elem2); face_inf1.swap(o.face_inf1); face_inf2.swap(o.face_inf2);
+   edge_vertices.swap(o.edge_vertices);
+   std::swap(Nodes, o.Nodes); std::swap(own_nodes, o.own_nodes); std::swap(sequence, o.sequence);
+   std::swap(attributes, o.attributes); std::swap(bdr_attributes, o.bdr_attributes);
+   MFEM_VERIFY(!Nodes && !o.Nodes, "mfem_amd: a Mesh with nodes cannot be moved (its nodal space points to it)");
+}
+
+Mesh Mesh::MakeCartesian3D(int nx, int ny, int nz, Element::Type type, real_t sx, real_t sy, real_t sz, bool sfc)
+{
+   MFEM_VERIFY(type == Element::HEXAHEDRON, "mfem_amd: only hexahedral meshes");
+   Mesh m;
+   m.Make3D(nx, ny, nz, sx, sy, sz, sfc);
+   return m;
+}
+
+// mesh/mesh.cpp:3684-3964
+void Mesh::Make3D(int nx, int ny, int nz, real_t sx, real_t sy, real_t sz, bool sfc_ordering)
+{
+   MFEM_VERIFY(nx > 0 && ny > 0 && nz > 0, "invalid grid");
+   Dim = spaceDim = 3;
+   vertices.clear(); elements.clear(); elem_attr.clear(); boundary.clear(); bdr_attr.clear();
+   vertices.reserve((size_t)3*(nx + 1)*(ny + 1)*(nz + 1));
+   for (int z = 0; z <= nz; z++)
+      for (int y = 0; y <= ny; y++)
+         for (int x = 0; x <= nx; x++)
+         {
+            vertices.push_back(((real_t)x/nx)*sx);
+            vertices.push_back(((real_t)y/ny)*sy);
+            vertices.push_back(((real_t)z/nz)*sz);
+         }
+   auto VTX = [&](int x, int y, int z) { return x + (y + z*(ny + 1))*(nx + 1); };
+   auto add_hex = [&](int x, int y, int z)
+   {
+      const int ind[8] = { VTX(x, y, z), VTX(x+1, y, z), VTX(x+1, y+1, z), VTX(x, y+1, z),
+                           VTX(x, y, z+1), VTX(x+1, y, z+1), VTX(x+1, y+1, z+1), VTX(x, y+1, z+1)
+                         };
+      elements.insert(elements.end(), ind, ind + 8); elem_attr.push_back(1);
+   };
+   elements.reserve((size_t)8*nx*ny*nz);
+   if (sfc_ordering)
+   {
+      std::vector<int> sfc;
+      grid_sfc_ordering_3d(nx, ny, nz, sfc);
+      MFEM_VERIFY((int)sfc.size() == 3*nx*ny*nz, "");
+      for (int k = 0; k < nx*ny*nz; k++) { add_hex(sfc[3*k], sfc[3*k+1], sfc[3*k+2]); }
+   }
+   else
+   {
+      for (int z = 0; z < nz; z++) for (int y = 0; y < ny; y++) for (int x = 0; x < nx; x++) { add_hex(x, y, z); }
+   }
+   auto add_bdr = [&](int a, int b, int c, int d, int attr)
+   { const int v[4] = {a, b, c, d}; boundary.insert(boundary.end(), v, v + 4); bdr_attr.push_back(attr); };
+   // bottom 1, top 6, left 5, right 3, front 2, back 4
+   for (int y = 0; y < ny; y++) for (int x = 0; x < nx; x++)
+      { add_bdr(VTX(x, y, 0), VTX(x, y+1, 0), VTX(x+1, y+1, 0), VTX(x+1, y, 0), 1); }
+   for (int y = 0; y < ny; y++) for (int x = 0; x < nx; x++)
+      { add_bdr(VTX(x, y, nz), VTX(x+1, y, nz), VTX(x+1, y+1, nz), VTX(x, y+1, nz), 6); }
+   for (int z = 0; z < nz; z++) for (int y = 0; y < ny; y++)
+      { add_bdr(VTX(0, y, z), VTX(0, y, z+1), VTX(0, y+1, z+1), VTX(0, y+1, z), 5); }
+   for (int z = 0; z < nz; z++) for (int y = 0; y < ny; y++)
+      { add_bdr(VTX(nx, y, z), VTX(nx, y+1, z), VTX(nx, y+1, z+1), VTX(nx, y, z+1), 3); }
+   for (int x = 0; x < nx; x++) for (int z = 0; z < nz; z++)
+      { add_bdr(VTX(x, 0, z), VTX(x+1, 0, z), VTX(x+1, 0, z+1), VTX(x, 0, z+1), 2); }
+   for (int x = 0; x < nx; x++) for (int z = 0; z < nz; z++)
+      { add_bdr(VTX(x, ny, z), VTX(x, ny, z+1), VTX(x+1, ny, z+1), VTX(x+1, ny, z), 4); }
+   FinalizeTopology();
+}
+
+namespace
+{
+struct Key3 { int a, b, c; bool operator==(const Key3 &o) const { return a == o.a && b == o.b && c == o.c; } };
+struct Key3Hash { size_t operator()(const Key3 &k) const { return ((size_t)k.a*73856093u) ^ ((size_t)k.b*19349663u) ^ ((size_t)k.c*83492791u); } };
+// a quadrilateral face is identified by its three smallest vertices (general/stable3d.cpp:140-165)
+inline Key3 quad_key(int r, int c, int f, int t)
+{
+   int v[4] = {r, c, f, t};
+   std::sort(v, v + 4);
+   return {v[0], v[1], v[2]};
+}
+}
+
+// mesh/mesh.cpp:3503-3607: faces (GetElementToFaceTable :8760-8864, GenerateFaces :8532-),
+// then edges (GetElementToEdgeTable :8315-8352).  Both are numbered by first appearance when
+// looping elements in order and their local faces / edges in order (general/stable3d.cpp:64-95,
+// general/table.cpp:623-645).
+void Mesh::FinalizeTopology()
+{
+   const int ne = GetNE(), nbe = GetNBE(), nv = GetNV();
+   for (int v : elements) { MFEM_VERIFY(v >= 0 && v < nv, "invalid vertex index in element"); }
+   for (int v : boundary) { MFEM_VERIFY(v >= 0 && v < nv, "invalid vertex index in boundary element"); }
+   std::unordered_map<Key3, int, Key3Hash> ftab;
+   ftab.reserve((size_t)3*ne + nbe);
+   el_to_face.assign((size_t)6*ne, -1);
+   face_vertices.clear(); face_elem1.clear(); face_elem2.clear(); face_inf1.clear(); face_inf2.clear();
+   for (int e = 0; e < ne; e++)
+   {
+      const int *v = &elements[8*e];
+      for (int j = 0; j < 6; j++)
+      {
+         const int fv[4] = { v[hex_faces[j][0]], v[hex_faces[j][1]], v[hex_faces[j][2]], v[hex_faces[j][3]] };
+         auto ins = ftab.emplace(quad_key(fv[0], fv[1], fv[2], fv[3]), (int)face_elem1.size());
+         const int gf = ins.first->second;
+         el_to_face[6*e + j] = gf;
+         if (ins.second)       // first element on this face defines the base orientation (:8505-8515)
+         {
+            face_vertices.insert(face_vertices.end(), fv, fv + 4);
+            face_elem1.push_back(e); face_inf1.push_back(64*j);
+            face_elem2.push_back(-1); face_inf2.push_back(-1);
+         }
+         else
+         {
+            MFEM_VERIFY(face_elem2[gf] < 0, "Invalid mesh topology.  Interior quadrilateral face found connecting elements "
+                        << face_elem1[gf] << ", " << face_elem2[gf] << " and " << e << ".");
+            face_elem2[gf] = e;
+            face_inf2[gf] = 64*j + GetQuadOrientation(&face_vertices[4*gf], fv);
+         }
+      }
+   }
+   NumOfFaces = (int)face_elem1.size();
+   be_to_face.resize(nbe);
+   for (int b = 0; b < nbe; b++)
+   {
+      const int *v = &boundary[4*b];
+      auto it = ftab.find(quad_key(v[0], v[1], v[2], v[3]));
+      MFEM_VERIFY(it != ftab.end(), "boundary element " << b << " is not a face of the mesh");
+      be_to_face[b] = it->second;
+   }
+   // edges
+   std::unordered_map<uint64_t, int> etab;
+   etab.reserve((size_t)4*ne);
+   edge_vertices.clear();
+   auto edge_id = [&](int a, int b, bool insert)
+   {
+      if (a > b) { std::swap(a, b); }
+      const uint64_t key = ((uint64_t)(uint32_t)a << 32) | (uint32_t)b;
+      auto it = etab.find(key);
+      if (it != etab.end()) { return it->second; }
+      MFEM_VERIFY(insert, "boundary edge is not an edge of the mesh");
+      const int id = (int)etab.size();
+      etab.emplace(key, id);
+      edge_vertices.push_back(a); edge_vertices.push_back(b);
+      return id;
+   };
+   el_to_edge.resize((size_t)12*ne);
+   for (int e = 0; e < ne; e++)
+   {
+      const int *v = &elements[8*e];
+      for (int j = 0; j < 12; j++) { el_to_edge[12*e + j] = edge_id(v[hex_edges[j][0]], v[hex_edges[j][1]], true); }
+   }
+   NumOfEdges = (int)etab.size();
+   bel_to_edge.resize((size_t)4*nbe);
+   for (int b = 0; b < nbe; b++)
+   {
+      const int *v = &boundary[4*b];
+      for (int j = 0; j < 4; j++) { bel_to_edge[4*b + j] = edge_id(v[quad_edges[j][0]], v[quad_edges[j][1]], false); }
+   }
+   SetAttributes();
+   sequence++;
+}
+
+void Mesh::SetAttributes()
+{
+   auto uniq = [](const std::vector<int> &src, Array<int> &dst)
+   {
+      std::vector<int> t(src); std::sort(t.begin(), t.end()); t.erase(std::unique(t.begin(), t.end()), t.end());
+      dst.SetSize((int)t.size());
+      for (size_t i = 0; i < t.size(); i++) { dst[(int)i] = t[i]; }
+   };
+   uniq(elem_attr, attributes); uniq(bdr_attr, bdr_attributes);
+   if (attributes.Size() && attributes[0] <= 0) { MFEM_WARNING("Non-positive attributes in the domain!"); }
+   if (bdr_attributes.Size() && bdr_attributes[0] <= 0) { MFEM_WARNING("Non-positive attributes on the boundary!"); }
+}
+
+// mesh/mesh.cpp:7377-7423
+int Mesh::GetQuadOrientation(const int *base, const int *test)
+{
+   int i;
+   for (i = 0; i < 4; i++) { if (test[i] == base[0]) { break; } }
+   MFEM_VERIFY(i < 4, "Mesh::GetQuadOrientation: faces do not match");
+   return (test[(i + 1) % 4] == base[1]) ? 2*i : 2*i + 1;
+}
+int Mesh::GetElementFaceOrientation(int e, int lf) const
+{
+   const int gf = el_to_face[6*e + lf];
+   if (face_elem1[gf] == e && face_inf1[gf]/64 == lf) { return face_inf1[gf] % 64; }
+   MFEM_ASSERT(face_elem2[gf] == e, "internal error");
+   return face_inf2[gf] % 64;
+}
+
+void Mesh::MarkExternalBoundaries(Array<int> &bdr_marker, bool excl) const
+{
+   const int max_bdr_attr = bdr_attributes.Max();
+   MFEM_VERIFY(bdr_marker.Size() >= max_bdr_attr, "bdr_marker must be at least bdr_attriburtes.Max() in length");
+   std::vector<char> interior(max_bdr_attr, 0), exterior(max_bdr_attr, 0);
+   for (int be = 0; be < GetNBE(); be++)
+   {
+      const int f = be_to_face[be];
+      (face_elem2[f] >= 0 ? interior : exterior)[bdr_attr[be] - 1] = 1;
+   }
+   for (int b = 0; b < max_bdr_attr; b++)
+   { if (bdr_marker[b] == 0 && exterior[b] && (!excl || !interior[b])) { bdr_marker[b] = 1; } }
+}
+
+// a hexahedron with the reference vertex order has a positive Jacobian at its first vertex
+void Mesh::CheckElementOrientation()
+{
+   if (Nodes) { return; }
+   for (int e = 0; e < GetNE(); e++)
+   {
+      const int *v = &elements[8*e];
+      const real_t *p0 = &vertices[3*v[0]], *p1 = &vertices[3*v[1]], *p3 = &vertices[3*v[3]], *p4 = &vertices[3*v[4]];
+      real_t a[3], b[3], c[3];
+      for (int k = 0; k < 3; k++) { a[k] = p1[k] - p0[k]; b[k] = p3[k] - p0[k]; c[k] = p4[k] - p0[k]; }
+      const real_t det = a[0]*(b[1]*c[2] - b[2]*c[1]) - a[1]*(b[0]*c[2] - b[2]*c[0]) + a[2]*(b[0]*c[1] - b[1]*c[0]);
+      MFEM_VERIFY(det > 0.0, "mfem_amd: element " << e << " is inverted; fixing orientations is not built");
+   }
+}
+
+// ---- files -----------------------------------------------------------------------------
+namespace
+{
+void skip_comment_lines(std::istream &is)
+{
+   for (;;)
+   {
+      is >> std::ws;
+      if (is.peek() != '#') { break; }
+      is.ignore(1 << 20, '\n');
+   }
+}
+}
+
+Mesh::Mesh(const std::string &filename, int, int refine, bool)
+{
+   std::ifstream in(filename);
+   if (!in) { MFEM_ABORT("Mesh file not found: " << filename << '\n'); }
+   Load(in, refine);
+}
+
+// mesh/mesh.cpp:4944-5070 (Loader), mesh/mesh_readers.cpp:41- (ReadMFEMMesh), :1355- (INLINE)
+void Mesh::Load(std::istream &input, int)
+{
+   std::string header;
+   std::getline(input, header);
+   while (!header.empty() && (header.back() == '\r' || header.back() == ' ')) { header.pop_back(); }
+   if (header == "MFEM INLINE mesh v1.0")
+   {
+      int nx = -1, ny = -1, nz = -1; real_t sx = -1, sy = -1, sz = -1; std::string type;
+      for (;;)
+      {
+         skip_comment_lines(input);
+         std::string name, eq;
+         if (!(input >> name)) { break; }
+         input >> std::ws;
+         MFEM_VERIFY(input.get() == '=', "Inline mesh expected '=' after keyword " << name);
+         if (name == "nx") { input >> nx; }
+         else if (name == "ny") { input >> ny; }
+         else if (name == "nz") { input >> nz; }
+         else if (name == "sx") { input >> sx; }
+         else if (name == "sy") { input >> sy; }
+         else if (name == "sz") { input >> sz; }
+         else if (name == "type") { input >> type; }
+         else { MFEM_ABORT("unrecognized keyword (" << name << ") in inline mesh format.  Allowed keywords are: nx, ny, nz, type, sx, sy, sz"); }
+      }
+      MFEM_VERIFY(type == "hex", "mfem_amd: inline mesh type '" << type << "' (only 'hex' is built)");
+      MFEM_VERIFY(nx > 0 && ny > 0 && nz > 0 && sx > 0.0 && sy > 0.0 && sz > 0.0,
+                  "invalid 3D inline mesh format.  nx, ny, nz, sx, sy, and sz must be positive");
+      Make3D(nx, ny, nz, sx, sy, sz, true);
+      return;
+   }
+   MFEM_VERIFY(header == "MFEM mesh v1.0" || header == "MFEM mesh v1.2" || header == "MFEM mesh v1.3",
+               "mfem_amd: unsupported mesh format: '" << header << "'");
+   std::string ident;
+   skip_comment_lines(input); input >> ident;
+   MFEM_VERIFY(ident == "dimension", "invalid mesh file");
+   input >> Dim;
+   MFEM_VERIFY(Dim == 3, "mfem_amd: only 3D hexahedral meshes");
+   skip_comment_lines(input); input >> ident;
+   MFEM_VERIFY(ident == "elements", "invalid mesh file");
+   int n; input >> n;
+   elements.resize((size_t)8*n); elem_attr.resize(n);
+   for (int e = 0; e < n; e++)
+   {
+      int geom; input >> elem_attr[e] >> geom;
+      MFEM_VERIFY(geom == Geometry::CUBE, "mfem_amd: element " << e << " is not a hexahedron (geometry " << geom << ")");
+      for (int k = 0; k < 8; k++) { input >> elements[8*e + k]; }
+   }
+   skip_comment_lines(input); input >> ident;
+   MFEM_VERIFY(ident == "boundary", "invalid mesh file");
+   input >> n;
+   boundary.resize((size_t)4*n); bdr_attr.resize(n);
+   for (int b = 0; b < n; b++)
+   {
+      int geom; input >> bdr_attr[b] >> geom;
+      MFEM_VERIFY(geom == Geometry::SQUARE, "mfem_amd: boundary element " << b << " is not a quadrilateral");
+      for (int k = 0; k < 4; k++) { input >> boundary[4*b + k]; }
+   }
+   skip_comment_lines(input); input >> ident;
+   MFEM_VERIFY(ident == "vertices", "invalid mesh file");
+   int nv; input >> nv;
+   vertices.assign((size_t)3*nv, 0.0);
+   skip_comment_lines(input);
+   bool curved = false;
+   if (std::isdigit(input.peek()))
+   {
+      input >> spaceDim;
+      MFEM_VERIFY(spaceDim == 3, "mfem_amd: space dimension must be 3");
+      for (int i = 0; i < 3*nv; i++) { input >> vertices[i]; }
+      skip_comment_lines(input);
+      if (input >> ident) { curved = (ident == "nodes"); }
+   }
+   else { input >> ident; MFEM_VERIFY(ident == "nodes", "invalid mesh file"); curved = true; }
+   MFEM_VERIFY(input.good() || input.eof(), "error reading the mesh file");
+   FinalizeTopology();
+   if (curved)
+   {
+      // GridFunction(Mesh*, istream&): fem/gridfunc.cpp, space header of fem/fespace.cpp Load
+      std::string fecname; int vdim = 0, ord = 0;
+      skip_comment_lines(input); input >> ident;
+      MFEM_VERIFY(ident == "FiniteElementSpace", "invalid nodes header");
+      input >> ident; MFEM_VERIFY(ident == "FiniteElementCollection:", "invalid nodes header"); input >> fecname;
+      input >> ident; MFEM_VERIFY(ident == "VDim:", "invalid nodes header"); input >> vdim;
+      input >> ident; MFEM_VERIFY(ident == "Ordering:", "invalid nodes header"); input >> ord;
+      MFEM_VERIFY(vdim == 3, "mfem_amd: nodes must have 3 components");
+      FiniteElementCollection *nfec = FiniteElementCollection::New(fecname.c_str());
+      FiniteElementSpace *nfes = new FiniteElementSpace(this, nfec, 3, ord);
+      Nodes = new GridFunction(nfes); Nodes->MakeOwner(nfec); own_nodes = true;
+      real_t *nd = Nodes->HostWrite();
+      for (int i = 0; i < Nodes->Size(); i++) { input >> nd[i]; }
+      MFEM_VERIFY(!input.fail(), "error reading the mesh nodes");
+      // vertices := nodal values at the vertex dofs (Loader, mesh.cpp: SetVerticesFromNodes)
+      for (int v = 0; v < nv; v++) for (int c = 0; c < 3; c++) { vertices[3*v + c] = nd[nfes->DofToVDof(v, c)]; }
+   }
+   else { CheckElementOrientation(); }
+}
+
+// ---- nodes ---------------------------------------------------------------------------
+const FiniteElementSpace *Mesh::GetNodalFESpace() const { return Nodes ? Nodes->FESpace() : nullptr; }
+
+void Mesh::EnsureNodes()
+{
+   if (!Nodes) { SetCurvature(1, false, -1, Ordering::byVDIM); }
+}
+
+namespace internal
+{
+// values of a tensor Lagrange interpolant: out(jx,jy,jz,c) = sum_i P[jx][ix]P[jy][iy]P[jz][iz] in(ix,iy,iz,c),
+// P* are (nout x nin) row-major; data layout: index (ix + nin*(iy + nin*iz)) + nin^3*c.
+void TensorInterp3(int nin, int nout, const real_t *Px, const real_t *Py, const real_t *Pz,
+                    const real_t *in, real_t *out)
+{
+   std::vector<real_t> t1((size_t)nout*nin*nin), t2((size_t)nout*nout*nin);
+   const int nin3 = nin*nin*nin, nout3 = nout*nout*nout;
+   for (int c = 0; c < 3; c++)
+   {
+      const real_t *u = in + (size_t)c*nin3; real_t *o = out + (size_t)c*nout3;
+      for (int iz = 0; iz < nin; iz++) for (int iy = 0; iy < nin; iy++) for (int jx = 0; jx < nout; jx++)
+            {
+               real_t s = 0; for (int ix = 0; ix < nin; ix++) { s += Px[jx*nin + ix]*u[ix + nin*(iy + nin*iz)]; }
+               t1[jx + nout*(iy + nin*iz)] = s;
+            }
+      for (int iz = 0; iz < nin; iz++) for (int jy = 0; jy < nout; jy++) for (int jx = 0; jx < nout; jx++)
+            {
+               real_t s = 0; for (int iy = 0; iy < nin; iy++) { s += Py[jy*nin + iy]*t1[jx + nout*(iy + nin*iz)]; }
+               t2[jx + nout*(jy + nout*iz)] = s;
+            }
+      for (int jz = 0; jz < nout; jz++) for (int jy = 0; jy < nout; jy++) for (int jx = 0; jx < nout; jx++)
+            {
+               real_t s = 0; for (int iz = 0; iz < nin; iz++) { s += Pz[jz*nin + iz]*t2[jx + nout*(jy + nout*iz)]; }
+               o[jx + nout*(jy + nout*jz)] = s;
+            }
+   }
+}
+// P[j][i] = L_i(pts[j]) for the Lagrange basis on `nodes`
+std::vector<real_t> InterpMatrix(const std::vector<real_t> &nodes, const std::vector<real_t> &pts)
+{
+   const int nin = (int)nodes.size(), nout = (int)pts.size();
+   std::vector<real_t> B((size_t)nin*nout), G((size_t)nin*nout), P((size_t)nin*nout);
+   LagrangeBasisTables(nin - 1, nodes.data(), nout, pts.data(), B.data(), G.data());
+   for (int j = 0; j < nout; j++) for (int i = 0; i < nin; i++) { P[j*nin + i] = B[j + nout*i]; }
+   return P;
+}
+
+// Lexicographic nodal coordinates of every element of the current geometry:
+// returns D (nodes per direction) and fills xe[(ix + D*(iy + D*iz)) + D^3*c + 3*D^3*e].
+int ElementNodesLex(const Mesh &mesh, std::vector<real_t> &xe)
+{
+   const int ne = mesh.GetNE();
+   const GridFunction *nodes = mesh.GetNodes();
+   if (!nodes)
+   {
+      static const int lex2v[8] = {0, 1, 3, 2, 4, 5, 7, 6};
+      xe.resize((size_t)24*ne);
+      for (int e = 0; e < ne; e++)
+      {
+         const int *v = mesh.GetElementVertices(e);
+         for (int l = 0; l < 8; l++) for (int c = 0; c < 3; c++) { xe[(size_t)24*e + l + 8*c] = mesh.GetVertex(v[lex2v[l]])[c]; }
+      }
+      return 2;
+   }
+   const FiniteElementSpace *nfes = nodes->FESpace();
+   const FiniteElement *fe = nfes->GetTypicalFE();
+   const int D = fe->GetOrder() + 1, nd = D*D*D;
+   const Array<int> &dmap = fe->GetDofMap();
+   const real_t *nv = nodes->HostRead();
+   xe.resize((size_t)3*nd*ne);
+   for (int e = 0; e < ne; e++)
+   {
+      const int *dofs = nfes->ElementDofs(e);
+      for (int l = 0; l < nd; l++)
+      {
+         const int g = dofs[dmap[l]];
+         for (int c = 0; c < 3; c++) { xe[(size_t)3*nd*e + l + nd*c] = nv[nfes->DofToVDof(g, c)]; }
+      }
+   }
+   return D;
+}
+} // namespace internal
+using internal::TensorInterp3; using internal::InterpMatrix; using internal::ElementNodesLex;
+
+// Store lexicographic element values into a nodal grid function, elements in order (shared
+// dofs are written by every element that has them; the last writer wins, as in the reference).
+static void set_nodes_from_lex(GridFunction &gf, const std::vector<real_t> &xe)
+{
+   const FiniteElementSpace *nfes = gf.FESpace();
+   const FiniteElement *fe = nfes->GetTypicalFE();
+   const int nd = fe->GetDof();
+   const Array<int> &dmap = fe->GetDofMap();
+   real_t *nv = gf.HostWrite();
+   for (int e = 0; e < nfes->GetNE(); e++)
+   {
+      const int *dofs = nfes->ElementDofs(e);
+      for (int l = 0; l < nd; l++)
+      {
+         const int g = dofs[dmap[l]];
+         for (int c = 0; c < 3; c++) { nv[nfes->DofToVDof(g, c)] = xe[(size_t)3*nd*e + l + nd*c]; }
+      }
+   }
+}
+
+// mesh/mesh.cpp:7046-7077: new H1 nodal space of the given order; the current geometry is
+// interpolated at its nodes.
+void Mesh::SetCurvature(int order, bool discont, int space_dim, int ordering)
+{
+   MFEM_VERIFY(!discont, "mfem_amd: discontinuous nodal spaces are not built");
+   MFEM_VERIFY(space_dim == -1 || space_dim == 3, "mfem_amd: space dimension must be 3");
+   if (order <= 0) { Destroy(); return; }
+   std::vector<real_t> xe_old;
+   const int Dold = ElementNodesLex(*this, xe_old);
+   std::vector<real_t> old_nodes(Dold);
+   { std::vector<real_t> w(Dold); GaussLobattoPoints(Dold, old_nodes.data(), w.data()); }
+   H1_FECollection *nfec = new H1_FECollection(order, 3);
+   FiniteElementSpace *nfes = new FiniteElementSpace(this, nfec, 3, ordering);
+   GridFunction *nn = new GridFunction(nfes); nn->MakeOwner(nfec);
+   const int D = order + 1, nd = D*D*D, ndo = Dold*Dold*Dold;
+   const std::vector<real_t> P = InterpMatrix(old_nodes, nfes->GetTypicalFE()->Nodes1D());
+   std::vector<real_t> xe((size_t)3*nd*GetNE());
+   for (int e = 0; e < GetNE(); e++)
+   { TensorInterp3(Dold, D, P.data(), P.data(), P.data(), &xe_old[(size_t)3*ndo*e], &xe[(size_t)3*nd*e]); }
+   set_nodes_from_lex(*nn, xe);
+   Destroy();
+   Nodes = nn; own_nodes = true;
+   sequence++;
+}
+
+void Mesh::Transform(std::function<void(const Vector &, Vector &)> f)
+{
+   Vector x(3), y(3);
+   if (!Nodes)
+   {
+      for (int v = 0; v < GetNV(); v++)
+      {
+         for (int c = 0; c < 3; c++) { x(c) = vertices[3*v + c]; }
+         f(x, y);
+         for (int c = 0; c < 3; c++) { vertices[3*v + c] = y(c); }
+      }
+   }
+   else
+   {
+      const FiniteElementSpace *nfes = Nodes->FESpace();
+      real_t *nv = Nodes->HostReadWrite();
+      for (int i = 0; i < nfes->GetNDofs(); i++)
+      {
+         for (int c = 0; c < 3; c++) { x(c) = nv[nfes->DofToVDof(i, c)]; }
+         f(x, y);
+         for (int c = 0; c < 3; c++) { nv[nfes->DofToVDof(i, c)] = y(c); }
+      }
+      for (int v = 0; v < GetNV(); v++) for (int c = 0; c < 3; c++) { vertices[3*v + c] = nv[nfes->DofToVDof(v, c)]; }
+   }
+   sequence++;
+}
+
+// ---- uniform refinement (mesh/mesh.cpp:10141-10870, hexahedra) ---------------------------
+void Mesh::UniformRefinement(int)
+{
+   const int ne = GetNE(), nbe = GetNBE(), nv = GetNV();
+   // geometry of the coarse elements, to be interpolated onto the children
+   std::vector<real_t> xe_old; int Dn = 0;
+   if (Nodes) { Dn = ElementNodesLex(*this, xe_old); }
+   const int oedge = nv, oface = oedge + NumOfEdges, oelem = oface + NumOfFaces;
+   vertices.resize((size_t)3*(oelem + ne), 0.0);
+   auto average = [&](const int *vv, int n, int dst)
+   {
+      for (int c = 0; c < 3; c++)
+      {
+         real_t s = 0.0;
+         for (int k = 0; k < n; k++) { s += vertices[3*vv[k] + c]; }
+         vertices[3*dst + c] = s/n;
+      }
+   };
+   std::vector<int> new_el((size_t)64*ne), new_attr((size_t)8*ne);
+   for (int i = 0; i < ne; i++)
+   {
+      const int *v = &elements[8*i], *e = &el_to_edge[12*i], *f = &el_to_face[6*i];
+      int vv[8];
+      average(v, 8, oelem + i);
+      for (int fi = 0; fi < 6; fi++) { for (int k = 0; k < 4; k++) { vv[k] = v[hex_faces[fi][k]]; } average(vv, 4, oface + f[fi]); }
+      for (int ei = 0; ei < 12; ei++) { for (int k = 0; k < 2; k++) { vv[k] = v[hex_edges[ei][k]]; } average(vv, 2, oedge + e[ei]); }
+      const int E[12] = { oedge+e[0], oedge+e[1], oedge+e[2], oedge+e[3], oedge+e[4], oedge+e[5],
+                          oedge+e[6], oedge+e[7], oedge+e[8], oedge+e[9], oedge+e[10], oedge+e[11]
+                        };
+      const int F[6] = { oface+f[0], oface+f[1], oface+f[2], oface+f[3], oface+f[4], oface+f[5] };
+      const int C = oelem + i;
+      const int child[8][8] =
+      {
+         { v[0], E[0], F[0], E[3], E[8], F[1], C, F[4] },
+         { E[0], v[1], E[1], F[0], F[1], E[9], F[2], C },
+         { F[0], E[1], v[2], E[2], C, F[2], E[10], F[3] },
+         { E[3], F[0], E[2], v[3], F[4], C, F[3], E[11] },
+         { E[8], F[1], C, F[4], v[4], E[4], F[5], E[7] },
+         { F[1], E[9], F[2], C, E[4], v[5], E[5], F[5] },
+         { C, F[2], E[10], F[3], F[5], E[5], v[6], E[6] },
+         { F[4], C, F[3], E[11], E[7], F[5], E[6], v[7] }
+      };
+      for (int k = 0; k < 8; k++)
+      {
+         std::copy(child[k], child[k] + 8, &new_el[(size_t)64*i + 8*k]);
+         new_attr[8*i + k] = elem_attr[i];
+      }
+   }
+   std::vector<int> new_b((size_t)16*nbe), new_battr((size_t)4*nbe);
+   for (int i = 0; i < nbe; i++)
+   {
+      const int *v = &boundary[4*i], *e = &bel_to_edge[4*i];
+      const int qf = oface + be_to_face[i];
+      const int q[4][4] =
+      {
+         { v[0], oedge+e[0], qf, oedge+e[3] }, { oedge+e[0], v[1], oedge+e[1], qf },
+         { qf, oedge+e[1], v[2], oedge+e[2] }, { oedge+e[3], qf, oedge+e[2], v[3] }
+      };
+      for (int k = 0; k < 4; k++) { std::copy(q[k], q[k] + 4, &new_b[(size_t)16*i + 4*k]); new_battr[4*i + k] = bdr_attr[i]; }
+   }
+   elements.swap(new_el); elem_attr.swap(new_attr); boundary.swap(new_b); bdr_attr.swap(new_battr);
+   FinalizeTopology();
+   if (Nodes)
+   {
+      // children sub-boxes (hex_children table, mesh.cpp:10802-10812): child k occupies the
+      // half [h/2, (h+1)/2] per direction with (hx,hy,hz) below; its nodes are the parent's
+      // interpolant evaluated there (GridFunction::Update with the refinement operator).
+      static const int hx[8] = {0, 1, 1, 0, 0, 1, 1, 0}, hy[8] = {0, 0, 1, 1, 0, 0, 1, 1}, hz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+      FiniteElementSpace *nfes = Nodes->FESpace();
+      const std::vector<real_t> g = nfes->GetTypicalFE()->Nodes1D();
+      std::vector<real_t> lo(Dn), hi(Dn);
+      for (int j = 0; j < Dn; j++) { lo[j] = 0.5*g[j]; hi[j] = 0.5 + 0.5*g[j]; }
+      const std::vector<real_t> P0 = InterpMatrix(g, lo), P1 = InterpMatrix(g, hi);
+      const int nd = Dn*Dn*Dn;
+      std::vector<real_t> xe((size_t)3*nd*8*ne);
+      for (int i = 0; i < ne; i++)
+         for (int k = 0; k < 8; k++)
+         {
+            TensorInterp3(Dn, Dn, (hx[k] ? P1 : P0).data(), (hy[k] ? P1 : P0).data(), (hz[k] ? P1 : P0).data(),
+                           &xe_old[(size_t)3*nd*i], &xe[(size_t)3*nd*(8*i + k)]);
+         }
+      nfes->Update();
+      Nodes->SetSize(nfes->GetVSize());
+      set_nodes_from_lex(*Nodes, xe);
+      const real_t *nvv = Nodes->HostRead();
+      for (int v = 0; v < GetNV(); v++) for (int c = 0; c < 3; c++) { vertices[3*v + c] = nvv[nfes->DofToVDof(v, c)]; }
+   }
+}
+
+// ---- output (mesh/mesh.cpp:12225-12349) --------------------------------------------------
+void Mesh::Print(std::ostream &os) const
+{
+   os << "MFEM mesh v1.0\n"
+      "\n#\n# MFEM Geometry Types (see fem/geom.hpp):\n#\n"
+      "# POINT       = 0\n# SEGMENT     = 1\n# TRIANGLE    = 2\n# SQUARE      = 3\n"
+      "# TETRAHEDRON = 4\n# CUBE        = 5\n# PRISM       = 6\n# PYRAMID     = 7\n#\n";
+   os << "\ndimension\n" << Dim;
+   os << "\n\nelements\n" << GetNE() << '\n';
+   for (int e = 0; e < GetNE(); e++)
+   {
+      os << elem_attr[e] << ' ' << (int)Geometry::CUBE;
+      for (int k = 0; k < 8; k++) { os << ' ' << elements[8*e + k]; }
+      os << '\n';
+   }
+   os << "\nboundary\n" << GetNBE() << '\n';
+   for (int b = 0; b < GetNBE(); b++)
+   {
+      os << bdr_attr[b] << ' ' << (int)Geometry::SQUARE;
+      for (int k = 0; k < 4; k++) { os << ' ' << boundary[4*b + k]; }
+      os << '\n';
+   }
+   os << "\nvertices\n" << GetNV() << '\n';
+   if (!Nodes)
+   {
+      os << spaceDim << '\n';
+      for (int v = 0; v < GetNV(); v++) { os << vertices[3*v] << ' ' << vertices[3*v+1] << ' ' << vertices[3*v+2] << '\n'; }
+      os.flush();
+   }
+   else
+   {
+      os << "\nnodes\n";
+      Nodes->Save(os);
+   }
+}
+void Mesh::PrintInfo(std::ostream &os) const
+{
+   os << "Mesh: " << GetNE() << " hexahedra, " << GetNV() << " vertices, " << NumOfEdges << " edges, "
+      << NumOfFaces << " faces, " << GetNBE() << " boundary quadrilaterals"
+      << (Nodes ? ", nodes of order " : "") ;
+   if (Nodes) { os << Nodes->FESpace()->GetMaxElementOrder(); }
+   os << '\n';
+}
+std::ostream &operator<<(std::ostream &os, const Mesh &mesh) { mesh.Print(os); return os; }
+
+} // namespace mfem
