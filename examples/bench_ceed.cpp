@@ -1,0 +1,110 @@
+// bench_ceed -- the CEED bake-off problems (BP1 mass, BP3 / BP5 diffusion; scalar) and
+// kernels through the MFEM API surface of mfem_amd, set up as MFEM's
+// tests/benchmarks/bench_ceed.cpp does (Cartesian N^3 hex mesh with the default Hilbert
+// element ordering, H1 Gauss-Lobatto basis of order p, Gauss-Legendre 2p+3 or Gauss-Lobatto
+// 2p-1 rule, unit coefficient, Dirichlet on the whole boundary, f = 1).
+//
+//   bench_ceed -bp 3 -p 4 -n 12                 # operator apply ("kernel") and CG solve ("problem")
+//
+// Prints one line per phase with the known-answer quantities (|A x|, iterations, |X|) that
+// BASELINE.md tabulates for the reference, plus MDof/s.
+#include "mfem.hpp"
+#include <chrono>
+#include <cstdio>
+
+using namespace mfem;
+
+static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static int reps = 20, max_it = 2000, seed = 1;
+static double rtol = 1e-12;
+static bool jacobi = true, lex = false;
+
+static void run_case(int bp, int p, int N);
+
+int main(int argc, char *argv[])
+{
+   int bp = 3, p = 4, N = 12;
+   const char *device_config = "hip";
+   OptionsParser args(argc, argv);
+   args.AddOption(&bp, "-bp", "--bake-off-problem", "1 (mass), 3 (diffusion, q=p+2), 5 (diffusion, GLL q=p+1).");
+   args.AddOption(&p, "-p", "--order", "Polynomial degree (0: sweep p = 1..8).");
+   args.AddOption(&N, "-n", "--elements", "Elements per direction (0: 48/p, the known-answer table of BASELINE.md).");
+   args.AddOption(&reps, "-reps", "--repetitions", "Timed operator applications.");
+   args.AddOption(&max_it, "-mi", "--max-iter", "CG iteration limit.");
+   args.AddOption(&rtol, "-rtol", "--rel-tol", "CG relative tolerance.");
+   args.AddOption(&jacobi, "-jacobi", "--jacobi", "-no-jacobi", "--no-jacobi", "Jacobi preconditioner.");
+   args.AddOption(&lex, "-lex", "--lexicographic", "-sfc", "--space-filling-curve", "Element ordering of the mesh.");
+   args.AddOption(&seed, "-s", "--seed", "Seed of x.Randomize().");
+   args.AddOption(&device_config, "-d", "--device", "Device configuration string.");
+   args.Parse();
+   if (!args.Good()) { args.PrintUsage(std::cout); return 1; }
+   MFEM_VERIFY(bp == 1 || bp == 3 || bp == 5, "bp must be 1, 3 or 5");
+   Device device(device_config);
+   for (int q = (p ? p : 1); q <= (p ? p : 8); q++) { run_case(bp, q, N ? N : 48/q); }
+   return 0;
+}
+
+static void run_case(int bp, int p, int N)
+{
+   const bool GLL = bp == 5;
+   double t0 = now();
+   Mesh mesh = Mesh::MakeCartesian3D(N, N, N, Element::HEXAHEDRON, 1.0, 1.0, 1.0, !lex);
+   H1_FECollection fec(p, 3, BasisType::GaussLobatto);
+   FiniteElementSpace fes(&mesh, &fec);
+   IntegrationRules irs(0, GLL ? Quadrature1D::GaussLobatto : Quadrature1D::GaussLegendre);
+   const IntegrationRule *ir = &irs.Get(Geometry::CUBE, 2*p + (GLL ? -1 : 3));
+   ConstantCoefficient one(1.0);
+   const int dofs = fes.GetTrueVSize();
+   GridFunction x(&fes), y(&fes);
+   BilinearForm a(&fes);
+   a.SetAssemblyLevel(AssemblyLevel::PARTIAL);
+   if (bp == 1) { a.AddDomainIntegrator(new MassIntegrator(one, ir)); }
+   else { a.AddDomainIntegrator(new DiffusionIntegrator(one, ir)); }
+   a.Assemble();
+   double t_setup = now() - t0;
+
+   // kernel: y = A x (BilinearForm::Mult), x = Randomize(seed)
+   x.Randomize(seed);
+   a.Mult(x, y);
+   const double ynorm = y.Norml2();
+   x.Read(); y.Write();
+   internal::DeviceSync();
+   t0 = now();
+   for (int i = 0; i < reps; i++) { a.Mult(x, y); }
+   internal::DeviceSync();
+   const double t_apply = (now() - t0)/reps;
+   printf("{\"phase\": \"kernel\", \"bp\": %d, \"p\": %d, \"N\": %d, \"dofs\": %d, \"norm_Ax\": %.15e, \"ms_per_apply\": %.6f, "
+          "\"MDof/s\": %.3f, \"setup_s\": %.3f}\n", bp, p, N, dofs, ynorm, t_apply*1e3, 1e-6*dofs/t_apply, t_setup);
+
+   // problem: f = 1, homogeneous Dirichlet, (Jacobi-)CG to rtol
+   Array<int> ess_bdr(mesh.bdr_attributes.Max()), ess_tdof_list;
+   ess_bdr = 1;
+   fes.GetEssentialTrueDofs(ess_bdr, ess_tdof_list);
+   LinearForm b(&fes);
+   b.AddDomainIntegrator(new DomainLFIntegrator(one));
+   b.UseFastAssembly(true);
+   b.Assemble();
+   x = 0.0;
+   OperatorPtr A;
+   Vector B, X;
+   a.FormLinearSystem(ess_tdof_list, x, b, A, X, B);
+   OperatorJacobiSmoother M(a, ess_tdof_list);
+   CGSolver cg;
+   cg.SetRelTol(rtol); cg.SetAbsTol(0.0); cg.SetMaxIter(max_it); cg.SetPrintLevel(-1);
+   cg.SetOperator(*A);
+   if (jacobi) { cg.SetPreconditioner(M); }
+   cg.iterative_mode = false;
+   cg.Mult(B, X);                   // warm-up + the known answer
+   internal::DeviceSync();
+   t0 = now();
+   cg.Mult(B, X);
+   internal::DeviceSync();
+   const double t_solve = now() - t0;
+   const int its = cg.GetNumIterations();
+   printf("{\"phase\": \"problem\", \"bp\": %d, \"p\": %d, \"N\": %d, \"dofs\": %d, \"iterations\": %d, \"converged\": %d, "
+          "\"norm_X\": %.15e, \"norm_B\": %.15e, \"initial_norm\": %.15e, \"final_norm\": %.15e, \"solve_s\": %.6f, \"MDof_it/s\": %.3f}\n",
+          bp, p, N, dofs, its, (int)cg.GetConverged(), X.Norml2(), B.Norml2(), cg.GetInitialNorm(), cg.GetFinalNorm(),
+          t_solve, 1e-6*dofs*its/t_solve);
+   fflush(stdout);
+}

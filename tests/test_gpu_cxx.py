@@ -1,0 +1,74 @@
+"""The C++ host layer end to end on the GPU: ex1 and the bake-off drivers (examples/), built on
+the MFEM API surface of mfem_amd/host/mfem.hpp, against the reference's own outputs
+(unknown counts, iteration counts, (B r, r) values, |A x| for
+x.Randomize(1), |X|)."""
+import json
+import re
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+BIN = ROOT / "examples" / "bin"
+MESHES = ROOT / "tests" / "golden" / "meshes"
+ANCHORS = json.loads((ROOT / "tests" / "golden" / "baseline_anchors.json").read_text())
+
+pytestmark = pytest.mark.gpu
+
+
+def run(cmd, timeout=600):
+    out = subprocess.run([str(c) for c in cmd], capture_output=True, text=True, timeout=timeout, cwd=str(ROOT))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    return out.stdout
+
+
+def parse_ex1(txt):
+    unknowns = int(re.search(r"Number of finite element unknowns: (\d+)", txt).group(1))
+    hist = [float(m) for m in re.findall(r"Iteration :\s+\d+\s+\(B r, r\) = (\S+)", txt)]
+    return unknowns, hist
+
+
+# reference: BASELINE.md 2.1 (ex1 -pa -d cpu): unknowns, iterations, (Br,r)_0, (Br,r)_last
+EX1 = [("inline-hex.mesh", 3, 912673, 197, 1.84147e-05, 1.47345e-17),
+       ("toroid-hex.mesh", 3, 691488, 161, 6.14869e-05, 5.76421e-17)]
+
+
+@pytest.mark.parametrize("mesh,order,unknowns,its,nom0,nom_last", EX1)
+def test_ex1_matches_reference(mesh, order, unknowns, its, nom0, nom_last):
+    txt = run([BIN / "ex1", "-m", MESHES / mesh, "-o", order, "-pa", "-d", "hip", "-no-vis", "-no-save"])
+    n, hist = parse_ex1(txt)
+    assert n == unknowns
+    assert len(hist) - 1 == its                      # identical CG iteration count
+    assert abs(hist[0] - nom0) <= 2e-6*nom0          # the reference prints 6 significant digits
+    # 12 orders of magnitude below (Br,r)_0 the recurrence has accumulated rounding: same size, not same digits
+    assert abs(hist[-1] - nom_last) <= 0.1*nom_last
+
+
+def test_ex1_refuses_paths_outside_partial_assembly():
+    out = subprocess.run([str(BIN / "ex1"), "-m", str(MESHES / "inline-hex.mesh"), "-d", "hip", "-no-vis", "-no-save"],
+                         capture_output=True, text=True, timeout=300, cwd=str(ROOT))
+    assert out.returncode != 0 and "PARTIAL" in out.stderr      # aborts with a message, MFEM's convention
+    out = subprocess.run([str(BIN / "ex1"), "-m", str(MESHES / "inline-hex.mesh"), "-pa", "-no-vis", "-no-save"],
+                         capture_output=True, text=True, timeout=300, cwd=str(ROOT))
+    assert out.returncode != 0 and "no CPU path" in out.stderr  # default '-d cpu' is refused loudly
+
+
+@pytest.mark.parametrize("bp", [1, 3, 5])
+def test_bakeoff_known_answers(bp):
+    """|A x| (x.Randomize(1), MFEM dof numbering + Hilbert element order), Jacobi-PCG iterations at
+    rel tol 1e-12 and |X| for p = 1..8 against the reference's table."""
+    txt = run([BIN / "bench_ceed", "-bp", bp, "-p", 0, "-n", 0, "-reps", 3])
+    rows = [json.loads(l) for l in txt.splitlines() if l.startswith("{")]
+    ker = {r["p"]: r for r in rows if r["phase"] == "kernel"}
+    prob = {r["p"]: r for r in rows if r["phase"] == "problem"}
+    ref = {c["p"]: c for c in ANCHORS["cases"] if c["problem"] == f"bp{bp}"}
+    assert sorted(ker) == sorted(prob) == list(range(1, 9))
+    for p in range(1, 9):
+        assert ker[p]["dofs"] == ref[p]["dofs"]
+        assert abs(ker[p]["norm_Ax"] - ref[p]["norm_Ax"]) <= 1e-12*ref[p]["norm_Ax"], (p, ker[p]["norm_Ax"], ref[p]["norm_Ax"])
+        assert prob[p]["converged"] == 1
+        # at rel tol 1e-12 the stopping decision can sit in rounding noise: +-1
+        assert abs(prob[p]["iterations"] - ref[p]["pcg_its"]) <= max(1, ref[p]["pcg_its"]//10), (p, prob[p]["iterations"], ref[p]["pcg_its"])
+        assert abs(prob[p]["norm_X"] - ref[p]["norm_X"]) <= 1e-8*ref[p]["norm_X"]
