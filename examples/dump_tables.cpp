@@ -5,6 +5,9 @@
 //
 //   dump_tables <outdir> cart <nx> <ny> <nz> <sx> <sy> <sz> <sfc 0|1> <p> <rule 0 GL(2p+3) | 1 GLL(2p-1) | 2 default> <kind 0 mass|1 diffusion>
 //   dump_tables <outdir> file <mesh file> <refinements> <p> <rule> <kind>
+// Two optional trailing arguments "<varcoef 0|1> run" also run the device path through the C++
+// API (operator action on the reference's SplitMix input, diagonal, RHS, constrained
+// operator, Jacobi, PCG) and write the results next to the tables (needs the GPU).
 #include "mfem.hpp"
 #include <cstdio>
 using namespace mfem;
@@ -17,6 +20,16 @@ template <class T> static void dump(const char *name, const T *p, size_t n)
    if (!fp || fwrite(p, sizeof(T), n, fp) != n) { MFEM_ABORT("cannot write " << f); }
    fclose(fp);
 }
+
+static double smix(uint64_t seed, uint64_t i)
+{
+   uint64_t z = seed * 0x9E3779B97F4A7C15ULL + (i + 1) * 0xBF58476D1CE4E5B9ULL;
+   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+   z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+   z = z ^ (z >> 31);
+   return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+static double coef_fn(const Vector &x) { return 1.0 + x(0)*x(0) + x(1)*x(2); }
 
 int main(int argc, char **argv)
 {
@@ -85,6 +98,56 @@ int main(int argc, char **argv)
    dump("nodes_B.f64", nm.B.HostRead(), nm.B.Size()); dump("nodes_G.f64", nm.G.HostRead(), nm.G.Size());
    printf("NE=%d ndofs=%d nedges=%d nfaces=%d D1D=%d Q1D=%d ness=%d\n", NE, fes.GetNDofs(), mesh->GetNEdges(), mesh->GetNFaces(),
           maps.ndof, maps.nqpt, ess.Size());
+   if (argc > a + 4 && std::string(argv[a+4]) == "run")
+   {
+      const bool varcoef = atoi(argv[a+3]) != 0;
+      Device device("hip");
+      ConstantCoefficient one(1.0);
+      FunctionCoefficient fc(coef_fn);
+      Coefficient &Q = varcoef ? (Coefficient&)fc : (Coefficient&)one;
+      BilinearForm bf(&fes);
+      bf.SetAssemblyLevel(AssemblyLevel::PARTIAL);
+      BilinearFormIntegrator *bfi = (kind == 0) ? (BilinearFormIntegrator*)new MassIntegrator(Q, rule == 2 ? nullptr : ir)
+                                    : (BilinearFormIntegrator*)new DiffusionIntegrator(Q, rule == 2 ? nullptr : ir);
+      bf.AddDomainIntegrator(bfi);
+      bf.Assemble();
+      const int N = fes.GetVSize();
+      Vector x(N), y(N), xE(NE*ND), yE(NE*ND), diag(N), diagE(NE*ND);
+      for (int i = 0; i < N; i++) { x(i) = smix(1, i); }
+      bf.Mult(x, y);
+      R->Mult(x, xE); yE = 0.0; bfi->AddMultPA(xE, yE);          // E-vector level (dispatch-table signature)
+      bf.AssembleDiagonal(diag);
+      diagE = 0.0; bfi->AssembleDiagonalPA(diagE);
+      dump("y.f64", y.HostRead(), N); dump("xE.f64", xE.HostRead(), xE.Size()); dump("yE.f64", yE.HostRead(), yE.Size());
+      dump("diag.f64", diag.HostRead(), N); dump("diagE.f64", diagE.HostRead(), diagE.Size());
+      LinearForm b(&fes);
+      b.AddDomainIntegrator(new DomainLFIntegrator(one));
+      b.Assemble();
+      dump("b.f64", b.HostRead(), N);
+      GridFunction u(&fes); u = 0.0;
+      OperatorPtr A; Vector Bv, X;
+      bf.FormLinearSystem(ess, u, b, A, X, Bv);
+      dump("B_rhs.f64", Bv.HostRead(), N);
+      Vector cy(N); A->Mult(x, cy); dump("y_constrained.f64", cy.HostRead(), N);
+      OperatorJacobiSmoother M(bf, ess);
+      Vector mz(N); M.Mult(x, mz); dump("jacobi_x.f64", mz.HostRead(), N);
+      CGSolver cg;
+      cg.SetRelTol(kind == 0 ? 1e-10 : 1e-6); cg.SetAbsTol(0.0); cg.SetMaxIter(2000); cg.SetPrintLevel(-1);
+      cg.SetOperator(*A); cg.SetPreconditioner(M); cg.iterative_mode = false;
+      cg.Mult(Bv, X);
+      dump("X.f64", X.HostRead(), N);
+      dump("cg_hist.f64", cg.ResidualHistory().data(), cg.ResidualHistory().size());
+      // the same solve through the generic (unfused) CGSolver path: an operator the fused path does not recognise
+      struct Wrap : Operator { const Operator &A; Wrap(const Operator &a) : Operator(a.Height()), A(a) {} void Mult(const Vector &x, Vector &y) const override { A.Mult(x, y); } } wrap(*A);
+      CGSolver cg2;
+      cg2.SetRelTol(kind == 0 ? 1e-10 : 1e-6); cg2.SetAbsTol(0.0); cg2.SetMaxIter(2000); cg2.SetPrintLevel(-1);
+      cg2.SetOperator(wrap); cg2.SetPreconditioner(M); cg2.iterative_mode = false;
+      Vector X2(N); cg2.Mult(Bv, X2);
+      dump("X_generic.f64", X2.HostRead(), N);
+      const int its[4] = { cg.GetNumIterations(), (int)cg.GetConverged(), cg2.GetNumIterations(), (int)cg2.GetConverged() };
+      dump("cg_iters.i32", its, 4);
+      printf("run: its=%d (generic %d) |y|=%.15e |X|=%.15e\n", its[0], its[2], y.Norml2(), X.Norml2());
+   }
    delete mesh;
    return 0;
 }
