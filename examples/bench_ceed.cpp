@@ -74,8 +74,12 @@ static void run_case(int bp, int p, int N)
    for (int i = 0; i < reps; i++) { a.Mult(x, y); }
    internal::DeviceSync();
    const double t_apply = (now() - t0)/reps;
+   // algorithmic bytes of one L->L apply: NE*(C*Q^3*8 + 2*D^3*4) + N_L*20
+   const double D1 = p + 1, Q1 = ir->n1d, NE = (double)N*N*N;
+   const double bytes_apply = NE*((bp == 1 ? 1 : 6)*Q1*Q1*Q1*8 + 2*D1*D1*D1*4) + 20.0*dofs;
    printf("{\"phase\": \"kernel\", \"bp\": %d, \"p\": %d, \"N\": %d, \"dofs\": %d, \"norm_Ax\": %.15e, \"ms_per_apply\": %.6f, "
-          "\"MDof/s\": %.3f, \"setup_s\": %.3f}\n", bp, p, N, dofs, ynorm, t_apply*1e3, 1e-6*dofs/t_apply, t_setup);
+          "\"MDof/s\": %.3f, \"GB/s\": %.1f, \"hbm_frac\": %.4f, \"setup_s\": %.3f}\n", bp, p, N, dofs, ynorm, t_apply*1e3,
+          1e-6*dofs/t_apply, 1e-9*bytes_apply/t_apply, 1e-9*bytes_apply/t_apply/8000.0, t_setup);
 
    // problem: f = 1, homogeneous Dirichlet, (Jacobi-)CG to rtol
    Array<int> ess_bdr(mesh.bdr_attributes.Max()), ess_tdof_list;
@@ -103,8 +107,9 @@ static void run_case(int bp, int p, int N)
    const double t_solve = now() - t0;
    const int its = cg.GetNumIterations();
    printf("{\"phase\": \"problem\", \"bp\": %d, \"p\": %d, \"N\": %d, \"dofs\": %d, \"iterations\": %d, \"converged\": %d, "
-          "\"norm_X\": %.15e, \"norm_B\": %.15e, \"initial_norm\": %.15e, \"final_norm\": %.15e, \"solve_s\": %.6f, \"MDof_it/s\": %.3f}\n",
+          "\"norm_X\": %.15e, \"norm_B\": %.15e, \"initial_norm\": %.15e, \"final_norm\": %.15e, \"solve_s\": %.6f, \"MDof_it/s\": %.3f, "
+          "\"hbm_frac\": %.4f}\n",
           bp, p, N, dofs, its, (int)cg.GetConverged(), X.Norml2(), B.Norml2(), cg.GetInitialNorm(), cg.GetFinalNorm(),
-          t_solve, 1e-6*dofs*its/t_solve);
+          t_solve, 1e-6*dofs*its/t_solve, 1e-9*(bytes_apply + 96.0*dofs)*its/t_solve/8000.0);
    fflush(stdout);
 }
