@@ -13,6 +13,14 @@ if not _SO.exists():
         f"{_SO} is missing: build the HIP extension first "
         "(python -c 'import __graft_entry__ as g; g.build()' or make -C mfem_amd/csrc). "
         "mfem_amd has no CPU fallback.")
+# One HIP runtime per process: PyTorch ships its own libamdhip64 and the drivers here use torch
+# for device memory, so let torch load its runtime first -- the library's libamdhip64.so.7
+# dependency then resolves to the copy already in the process instead of a second runtime
+# (two runtimes do not share the device: whichever initialises second sees no GPU).
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
 lib = C.CDLL(str(_SO))
 
 i64, vp, dbl, cint = C.c_int64, C.c_void_p, C.c_double, C.c_int

@@ -33,8 +33,9 @@ namespace mfa
 
 // Register budget hint (waves per SIMD the kernel should fit, 2nd __launch_bounds__ argument
 // on AMD): at p <= 4 diffusion fits 3 waves/SIMD = 3 resident workgroups per CU.
-constexpr int minw_for(int KIND, int D)
+constexpr int minw_for(int KIND, int D, int PF = 0)
 {
+   if (PF > 0) { return KIND ? (D <= 6 ? 3 : 2) : (D <= 7 ? 4 : 3); }   // streamed pa_data: fewer live registers
    return KIND ? (D <= 5 ? 3 : D <= 7 ? 2 : 1) : (D <= 7 ? 3 : 2);
 }
 
@@ -51,8 +52,16 @@ constexpr int minw_for(int KIND, int D)
 // pa_data stream.
 // ABL (tuning builds only, tools/ablate.hip): 0 = the kernel; 1 = memory traffic only (loads +
 // stores, no contractions); 2 = contractions only (pa_data not read).
-template <int KIND, int D, int Q, int NBZ, bool GATHER, bool ACCUM, bool BLK = false, int ABL = 0, bool PERSIST = true>
-__global__ void __launch_bounds__(Q*Q*NBZ, minw_for(KIND, D))
+// PF > 0 (blocked layout only): pa_data is streamed through the z loop instead of being held
+// whole in registers -- PF z-slices (6 doubles per thread each) are in flight at any time;
+// slice qz+PF is requested when slice qz is consumed, and in the persistent schedule the ring
+// runs on into the next batch, so every wave keeps a steady stream of requests up through all
+// phases.  Frees 2*NC*(Q-PF) registers per thread: one more wave per SIMD at p >= 4.
+#ifndef MFA_VGPR_CAP
+#define MFA_VGPR_CAP
+#endif
+template <int KIND, int D, int Q, int NBZ, bool GATHER, bool ACCUM, bool BLK = false, int ABL = 0, bool PERSIST = true, int PF = 0>
+__global__ void __launch_bounds__(Q*Q*NBZ, minw_for(KIND, D, PF)) MFA_VGPR_CAP
 k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const BasisT<D*Q> bg,
            const double *__restrict__ Dq, const double *__restrict__ x,
            const int *__restrict__ gmap, double *__restrict__ yE)
@@ -94,7 +103,9 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
       if (KIND) { sG[i] = bg.g[i]; }
    }
 
+   static_assert(PF == 0 || (BLK && ABL == 0 && PF < Q), "streamed pa_data needs the blocked layout");
    double O[Q][NC];
+   double On[PF > 0 ? PF : 1][NC];        // first PF slices of the next batch (persistent schedule)
    double xv[NXV];
    int gi[NXV];
 
@@ -190,11 +201,32 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
       }
    };
 
+   // one z-slice of the blocked pa_data of batch bt (PF > 0)
+   auto load_slice = [&](const int64_t bt, const int qz, double (&dst)[NC])
+   {
+      if (KIND)
+      {
+         const double2 *Db = reinterpret_cast<const double2*>(Dq) + bt*(int64_t)(3*Q*NBZ*QQ) + tz*QQ + b*Q + a;
+#pragma unroll
+         for (int cp = 0; cp < 3; cp++)
+         {
+            const double2 v = Db[(qz*3 + cp)*(NBZ*QQ)];
+            dst[(2*cp) % NC] = v.x; dst[(2*cp + 1) % NC] = v.y;
+         }
+      }
+      else { dst[0] = Dq[bt*(int64_t)(Q*NBZ*QQ) + tz*QQ + b*Q + a + qz*(NBZ*QQ)]; }
+   };
+
    {
       const int64_t e = b0*NBZ + tz;
       load_gi(e);
       load_xv(e);
-      load_O(e, b0);
+      if (PF == 0) { load_O(e, b0); }
+      else
+      {
+#pragma unroll
+         for (int s = 0; s < PF; s++) { load_slice(b0, s, O[s]); }
+      }
    }
 
    for (int64_t bt = b0; bt < b1; bt += bstep)
@@ -314,6 +346,12 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
 #pragma unroll
       for (int qz = 0; qz < Q; qz++)
       {
+         if (PF > 0)
+         {
+            // request the slice PF steps ahead: of this batch, or (ring) of the next one
+            if (qz + PF < Q) { load_slice(bt, qz + PF, O[qz + PF < Q ? qz + PF : 0]); }
+            else if (PERSIST) { load_slice(btn, qz + PF - Q, On[qz + PF >= Q ? qz + PF - Q : 0]); }
+         }
          if (KIND)
          {
             double gX = 0.0, gY = 0.0, gZ = 0.0;
@@ -367,7 +405,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
       if (PERSIST)
       {
          load_xv(en);
-         load_O(en, btn);
+         if (PF == 0) { load_O(en, btn); }
       }
       __syncthreads();
 
@@ -421,6 +459,15 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
       // no barrier needed here: the next iteration writes sX (region A), whose last readers
       // (the transposed y contraction) are behind the barrier above; sV is next written
       // three barriers from now.
+      if (PF > 0 && PERSIST)
+      {
+#pragma unroll
+         for (int s = 0; s < PF; s++)
+         {
+#pragma unroll
+            for (int c = 0; c < NC; c++) { O[s][c] = On[s][c]; }
+         }
+      }
    }
 }
 
@@ -596,20 +643,50 @@ static int apply_mode(int KIND, int D, int Q)
    if (forced >= 0) { return forced; }
    // measured (profiles/r1/sweep_modes.txt): one batch per workgroup wins up to p = 7 (BP3);
    // the persistent round-robin schedule wins where registers allow one wave per SIMD only
-   return (KIND == 1 && (D >= 9 || (D == 8 && Q == 8))) ? 2 : 0;
+   return (KIND == 1 && (D >= 9 || (D == 8 && Q == 8) || (D == 6 && Q == 6))) ? 2 : 0;
 }
 
 typedef int (*apply_fn)(int64_t ne, const double *B, const double *G, const double *Dq,
                         const double *x, const int *gmap, double *yE, hipStream_t s);
 
-template <int KIND, int D, int Q, bool GATHER, bool ACCUM, bool BLK>
+// pa_data prefetch distance in z-slices (0 = hold all Q slices in registers); MFEM_AMD_APPLY_PF
+// overrides it (tuning aid; only the values compiled in are accepted).
+static int apply_pf(int KIND, int D, int Q)
+{
+   static int forced = -2;
+   if (forced == -2)
+   {
+      const char *v = getenv("MFEM_AMD_APPLY_PF");
+      forced = (v && *v >= '0' && *v <= '9') ? (*v - '0') : -1;
+   }
+   if (forced >= 0) { return forced; }
+   // measured (profiles/r1/sweep_pf_*.txt): streaming pays where the whole-column prefetch costs
+   // a wave of occupancy -- diffusion at p = 8 (501 -> 351 us at 1e7 dofs), and the collocated
+   // (Q = D) kernels at p = 5, 7, 8; everywhere else holding the column is as fast or faster
+   if (KIND == 1)
+   {
+      if (D >= 9) { return Q == D ? 3 : 2; }
+      if (D == 8 && Q == 8) { return 2; }
+      if (D == 6 && Q == 6) { return 3; }
+   }
+   return 0;
+}
+
+template <int KIND, int D, int Q, bool GATHER, bool ACCUM, bool BLK, int PF = 0>
 static int launch_apply(int64_t ne, const double *B, const double *G, const double *Dq,
                         const double *x, const int *gmap, double *yE, hipStream_t s)
 {
    constexpr int NBZ = nbz_for(Q);
+   if (BLK && GATHER && !ACCUM && PF == 0 && Q > 3)
+   {
+      // the hot path has streamed variants
+      const int pf = apply_pf(KIND, D, Q);
+      if (pf == 2) { return launch_apply<KIND, D, Q, GATHER, ACCUM, BLK, (BLK && GATHER && !ACCUM && Q > 3) ? 2 : 0>(ne, B, G, Dq, x, gmap, yE, s); }
+      if (pf == 3) { return launch_apply<KIND, D, Q, GATHER, ACCUM, BLK, (BLK && GATHER && !ACCUM && Q > 3) ? 3 : 0>(ne, B, G, Dq, x, gmap, yE, s); }
+   }
    const int mode = apply_mode(KIND, D, Q);   // 0 one batch per workgroup, 1 persistent/contiguous, 2 persistent/round-robin
-   auto kern = k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM, BLK, 0, true>;
-   auto kern1 = k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM, BLK, 0, false>;
+   auto kern = k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM, BLK, 0, true, PF>;
+   auto kern1 = k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM, BLK, 0, false, PF>;
    // resident workgroups on the current device (queried once per instantiation and device)
    static int resident[64] = {0};
    int dev = 0;

@@ -74,6 +74,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     import torch
     from mfem_amd import capi
+    torch.cuda.init()
     capi.call("mfem_amd_init", 0)
     for prob in a.problem.split(","):
         for p in [int(s) for s in a.p.split(",")]:
