@@ -44,6 +44,49 @@ k_gather_vdim(const int64_t n, const int nd, const int vd, const int byvdim,
 // into the transpose-gather epilogue).  marker/xin: rows with marker[i] != 0 take xin[i]
 // (ConstrainedOperator y[ess] = x[ess], linalg/operator.cpp:624-629).  skip: optional
 // device flag; non-zero -> whole kernel is a no-op (converged PCG).
+//
+// The kernel is bound by the latency of its dependent loads (offsets -> indices -> values),
+// not by bytes, so every thread works on SK rows at once, 256 rows apart (each load
+// instruction stays coalesced across the wave): all offsets first, then the first two index
+// entries of every row, then their values -- independent loads in flight together -- before
+// anything is added.  Rows with more than two contributions (edges, vertices) finish through
+// the unrolled row routine.  The additions stay sequential and left to right per row,
+// starting from 0: the reference's order, bit for bit.
+constexpr int SK = 4;
+
+template <int MODE>
+__device__ __forceinline__ double scatter_row(const int o0, const int o1, const int *__restrict__ indices,
+                                              const double *__restrict__ xE)
+{
+   double v = 0.0;
+   const int n = o1 - o0;
+   if (n <= 0) { return v; }
+   if (n <= 8)
+   {
+      int id[8];
+      double t[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) { id[k] = indices[o0 + (k < n ? k : (n > 0 ? n - 1 : 0))]; }
+#pragma unroll
+      for (int k = 0; k < 8; k++) { t[k] = xE[id[k] >= 0 ? id[k] : -1 - id[k]]; }
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+      {
+         if (k < n) { v += (id[k] >= 0 || MODE == 2) ? t[k] : -t[k]; }
+      }
+   }
+   else
+   {
+      for (int j = o0; j < o1; j++)
+      {
+         const int idx = indices[j];
+         const double t = xE[idx >= 0 ? idx : -1 - idx];
+         v += (idx >= 0 || MODE == 2) ? t : -t;
+      }
+   }
+   return v;
+}
+
 template <int MODE, bool DOT>
 __global__ void __launch_bounds__(256)
 k_scatter(const int64_t ndofs, const int *__restrict__ offsets,
@@ -55,56 +98,60 @@ k_scatter(const int64_t ndofs, const int *__restrict__ offsets,
    __shared__ double s4[4];
    if (skip && *skip) { return; }
    double prod = 0.0;
-   for (int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x; i < ndofs; i += (int64_t)gridDim.x*256)
+   for (int64_t base = (int64_t)blockIdx.x*(256*SK); base < ndofs; base += (int64_t)gridDim.x*(256*SK))
    {
-      const int o0 = offsets[i], o1 = offsets[i + 1];
-      const int n = o1 - o0;
-      double v = 0.0;
-      // The sum is sequential and left-to-right from 0 (the reference's order), but the
-      // loads are independent: fetch all indices, then all values, then add in order.
-      // Hex meshes have multiplicity 1 (interior), 2 (face), 4 (edge), 8 (vertex) on
-      // conforming interior dofs; anything longer takes the plain loop.
-      if (n <= 2)
+      int o0[SK], n[SK], i0[SK], i1[SK];
+      double t0[SK], t1[SK], v[SK];
+      const int64_t last = ndofs - 1;
+#pragma unroll
+      for (int j = 0; j < SK; j++)
       {
-         if (n > 0)
+         const int64_t i = base + threadIdx.x + j*256;
+         const int64_t ic = i < ndofs ? i : last;          // clamped: loads stay unconditional
+         o0[j] = offsets[ic];
+         n[j] = offsets[ic + 1] - o0[j];
+      }
+#pragma unroll
+      for (int j = 0; j < SK; j++)
+      {
+         i0[j] = n[j] > 0 ? indices[o0[j]] : 0;
+         i1[j] = n[j] > 1 ? indices[o0[j] + 1] : i0[j];
+      }
+#pragma unroll
+      for (int j = 0; j < SK; j++)
+      {
+         t0[j] = xE[i0[j] >= 0 ? i0[j] : -1 - i0[j]];
+         t1[j] = xE[i1[j] >= 0 ? i1[j] : -1 - i1[j]];
+      }
+#pragma unroll
+      for (int j = 0; j < SK; j++)
+      {
+         if (n[j] <= 2)
          {
-            const int i0 = indices[o0], i1 = indices[o1 - 1];
-            const double t0 = xE[i0 >= 0 ? i0 : -1 - i0], t1 = xE[i1 >= 0 ? i1 : -1 - i1];
-            v += (i0 >= 0 || MODE == 2) ? t0 : -t0;
-            if (n == 2) { v += (i1 >= 0 || MODE == 2) ? t1 : -t1; }
+            double a = 0.0;
+            if (n[j] > 0) { a += (i0[j] >= 0 || MODE == 2) ? t0[j] : -t0[j]; }
+            if (n[j] > 1) { a += (i1[j] >= 0 || MODE == 2) ? t1[j] : -t1[j]; }
+            v[j] = a;
+         }
+         else { v[j] = scatter_row<MODE>(o0[j], o0[j] + n[j], indices, xE); }
+      }
+#pragma unroll
+      for (int j = 0; j < SK; j++)
+      {
+         const int64_t i = base + threadIdx.x + j*256;
+         if (i < ndofs)
+         {
+            double r = v[j];
+            if (marker)
+            {
+               const unsigned char m = marker[i];        // 1: essential (owned) -> x; 2: essential ghost -> 0
+               if (m) { r = (m == 1) ? xin[i] : 0.0; }
+            }
+            if (MODE == 1) { r += y[i]; }
+            y[i] = r;
+            if (DOT) { prod += w[i]*r; }
          }
       }
-      else if (n <= 8)
-      {
-         int id[8];
-         double t[8];
-#pragma unroll
-         for (int k = 0; k < 8; k++) { id[k] = indices[o0 + (k < n ? k : n - 1)]; }
-#pragma unroll
-         for (int k = 0; k < 8; k++) { t[k] = xE[id[k] >= 0 ? id[k] : -1 - id[k]]; }
-#pragma unroll
-         for (int k = 0; k < 8; k++)
-         {
-            if (k < n) { v += (id[k] >= 0 || MODE == 2) ? t[k] : -t[k]; }
-         }
-      }
-      else
-      {
-         for (int j = o0; j < o1; j++)
-         {
-            const int idx = indices[j];
-            const double t = xE[idx >= 0 ? idx : -1 - idx];
-            v += (idx >= 0 || MODE == 2) ? t : -t;
-         }
-      }
-      if (marker)
-      {
-         const unsigned char m = marker[i];           // 1: essential (owned) -> x; 2: essential ghost -> 0
-         if (m) { v = (m == 1) ? xin[i] : 0.0; }
-      }
-      if (MODE == 1) { v += y[i]; }
-      y[i] = v;
-      if (DOT) { prod += w[i]*v; }
    }
    if (DOT)
    {
