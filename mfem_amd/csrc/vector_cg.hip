@@ -69,8 +69,18 @@ k_dot_partial(const int64_t n, const double *__restrict__ x, const double *__res
 // t, t+256, ... then the fixed block tree.
 __device__ __forceinline__ double final_sum(const double *partials, const int nb, double *s4)
 {
+   // eight independent loads in flight per thread (one workgroup reads up to 8192 partials:
+   // a chain of dependent loads here costs ~12 us per reduction); the additions keep the
+   // order t, t+256, t+512, ...
    double acc = 0.0;
-   for (int i = threadIdx.x; i < nb; i += 256) { acc += partials[i]; }
+   for (int i0 = threadIdx.x; i0 < nb; i0 += 256*8)
+   {
+      double t[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) { const int i = i0 + k*256; t[k] = partials[i < nb ? i : nb - 1]; }
+#pragma unroll
+      for (int k = 0; k < 8; k++) { if (i0 + k*256 < nb) { acc += t[k]; } }
+   }
    return block_sum_256(acc, s4);
 }
 

@@ -421,13 +421,25 @@ void Mesh::Load(std::istream &input, int)
       input >> ident; MFEM_VERIFY(ident == "VDim:", "invalid nodes header"); input >> vdim;
       input >> ident; MFEM_VERIFY(ident == "Ordering:", "invalid nodes header"); input >> ord;
       MFEM_VERIFY(vdim == 3, "mfem_amd: nodes must have 3 components");
-      FiniteElementCollection *nfec = FiniteElementCollection::New(fecname.c_str());
-      FiniteElementSpace *nfes = new FiniteElementSpace(this, nfec, 3, ord);
-      Nodes = new GridFunction(nfes); Nodes->MakeOwner(nfec); own_nodes = true;
-      real_t *nd = Nodes->HostWrite();
-      for (int i = 0; i < Nodes->Size(); i++) { input >> nd[i]; }
-      MFEM_VERIFY(!input.fail(), "error reading the mesh nodes");
+      if (fecname == "Cubic")
+      {
+         std::vector<real_t> raw;
+         real_t val;
+         while (input >> val) { raw.push_back(val); }
+         SetNodesFromLegacyCubic(raw, ord);
+      }
+      else
+      {
+         FiniteElementCollection *nfec = FiniteElementCollection::New(fecname.c_str());
+         FiniteElementSpace *nfes = new FiniteElementSpace(this, nfec, 3, ord);
+         Nodes = new GridFunction(nfes); Nodes->MakeOwner(nfec); own_nodes = true;
+         real_t *nd = Nodes->HostWrite();
+         for (int i = 0; i < Nodes->Size(); i++) { input >> nd[i]; }
+         MFEM_VERIFY(!input.fail(), "error reading the mesh nodes");
+      }
       // vertices := nodal values at the vertex dofs (Loader, mesh.cpp: SetVerticesFromNodes)
+      const FiniteElementSpace *nfes = Nodes->FESpace();
+      const real_t *nd = Nodes->HostRead();
       for (int v = 0; v < nv; v++) for (int c = 0; c < 3; c++) { vertices[3*v + c] = nd[nfes->DofToVDof(v, c)]; }
    }
    else { CheckElementOrientation(); }
@@ -537,17 +549,12 @@ static void set_nodes_from_lex(GridFunction &gf, const std::vector<real_t> &xe)
    }
 }
 
-// mesh/mesh.cpp:7046-7077: new H1 nodal space of the given order; the current geometry is
-// interpolated at its nodes.
-void Mesh::SetCurvature(int order, bool discont, int space_dim, int ordering)
+// New H1 nodal space of the given order whose nodes interpolate element-wise tensor Lagrange
+// data: xe_old holds, per element, (Dold^3 x 3) lexicographic values on the 1D points old_nodes.
+void Mesh::SetNodesFromElementValues(int order, int ordering, const std::vector<real_t> &old_nodes,
+                                     const std::vector<real_t> &xe_old)
 {
-   MFEM_VERIFY(!discont, "mfem_amd: discontinuous nodal spaces are not built");
-   MFEM_VERIFY(space_dim == -1 || space_dim == 3, "mfem_amd: space dimension must be 3");
-   if (order <= 0) { Destroy(); return; }
-   std::vector<real_t> xe_old;
-   const int Dold = ElementNodesLex(*this, xe_old);
-   std::vector<real_t> old_nodes(Dold);
-   { std::vector<real_t> w(Dold); GaussLobattoPoints(Dold, old_nodes.data(), w.data()); }
+   const int Dold = (int)old_nodes.size();
    H1_FECollection *nfec = new H1_FECollection(order, 3);
    FiniteElementSpace *nfes = new FiniteElementSpace(this, nfec, 3, ordering);
    GridFunction *nn = new GridFunction(nfes); nn->MakeOwner(nfec);
@@ -560,6 +567,75 @@ void Mesh::SetCurvature(int order, bool discont, int space_dim, int ordering)
    Destroy();
    Nodes = nn; own_nodes = true;
    sequence++;
+}
+
+// mesh/mesh.cpp:7046-7077: new H1 nodal space of the given order; the current geometry is
+// interpolated at its nodes.
+void Mesh::SetCurvature(int order, bool discont, int space_dim, int ordering)
+{
+   MFEM_VERIFY(!discont, "mfem_amd: discontinuous nodal spaces are not built");
+   MFEM_VERIFY(space_dim == -1 || space_dim == 3, "mfem_amd: space dimension must be 3");
+   if (order <= 0) { Destroy(); return; }
+   std::vector<real_t> xe_old;
+   const int Dold = ElementNodesLex(*this, xe_old);
+   std::vector<real_t> old_nodes(Dold), w(Dold);
+   GaussLobattoPoints(Dold, old_nodes.data(), w.data());
+   SetNodesFromElementValues(order, ordering, old_nodes, xe_old);
+}
+
+// Legacy "Cubic" nodal collection (CubicFECollection, fem/fe_coll.hpp:958-986): the same
+// entity layout as H1 P3 (1 dof per vertex, 2 per edge, 4 per face, 8 per element) but
+// equispaced nodes, its own local ordering (LagrangeHexFiniteElement(3),
+// fem/fe/fe_fixed_order.cpp:3079-3176) and its own orientation tables (fem/fe_coll.cpp:867-
+// 897).  The reference converts such nodes to an H1 Gauss-Lobatto space of the same order on
+// first use (Mesh::EnsureNodes, mesh/mesh.cpp:6994-7033); the reader does it at once.
+void Mesh::SetNodesFromLegacyCubic(const std::vector<real_t> &raw, int ordering)
+{
+   // (I,J,K) of the 64 native dofs; 1D index 0,1,2,3 sits at x = 0, 1, 1/3, 2/3
+   static const unsigned char IJK[64][3] =
+   {
+      {0,0,0},{1,0,0},{1,1,0},{0,1,0},{0,0,1},{1,0,1},{1,1,1},{0,1,1},
+      {2,0,0},{3,0,0},{1,2,0},{1,3,0},{2,1,0},{3,1,0},{0,2,0},{0,3,0},
+      {2,0,1},{3,0,1},{1,2,1},{1,3,1},{2,1,1},{3,1,1},{0,2,1},{0,3,1},
+      {0,0,2},{0,0,3},{1,0,2},{1,0,3},{1,1,2},{1,1,3},{0,1,2},{0,1,3},
+      {2,3,0},{3,3,0},{2,2,0},{3,2,0},{2,0,2},{3,0,2},{2,0,3},{3,0,3},
+      {1,2,2},{1,3,2},{1,2,3},{1,3,3},{3,1,2},{2,1,2},{3,1,3},{2,1,3},
+      {0,3,2},{0,2,2},{0,3,3},{0,2,3},{2,2,1},{3,2,1},{2,3,1},{3,3,1},
+      {2,2,2},{3,2,2},{3,3,2},{2,3,2},{2,2,3},{3,2,3},{3,3,3},{2,3,3}
+   };
+   static const int pos1d[4] = {0, 3, 1, 2};          // 1D dof index -> position among 0, 1/3, 2/3, 1
+   static const int sq_ind[8][4] = { {0,1,2,3},{0,2,1,3},{2,0,3,1},{1,0,3,2},{3,2,1,0},{3,1,2,0},{1,3,0,2},{2,3,0,1} };
+   const int nv = GetNV(), NE = GetNE();
+   const int ndofs = nv + 2*NumOfEdges + 4*NumOfFaces + 8*NE;
+   MFEM_VERIFY((int)raw.size() == 3*ndofs, "legacy Cubic nodes: " << raw.size() << " values, expected " << 3*ndofs);
+   auto val = [&](int dof, int c) { return ordering == Ordering::byNODES ? raw[dof + (size_t)c*ndofs] : raw[(size_t)dof*3 + c]; };
+   std::vector<real_t> xe((size_t)3*64*NE);
+   for (int e = 0; e < NE; e++)
+   {
+      const int *v = &elements[8*e];
+      int dofs[64], o = 0;
+      for (int i = 0; i < 8; i++) { dofs[o++] = v[i]; }
+      for (int i = 0; i < 12; i++)
+      {
+         const bool pos = v[hex_edges[i][0]] < v[hex_edges[i][1]];
+         const int base = nv + 2*el_to_edge[12*e + i];
+         dofs[o++] = base + (pos ? 0 : 1); dofs[o++] = base + (pos ? 1 : 0);
+      }
+      for (int i = 0; i < 6; i++)
+      {
+         const int *ind = sq_ind[GetElementFaceOrientation(e, i)];
+         const int base = nv + 2*NumOfEdges + 4*el_to_face[6*e + i];
+         for (int j = 0; j < 4; j++) { dofs[o++] = base + ind[j]; }
+      }
+      for (int j = 0; j < 8; j++) { dofs[o++] = nv + 2*NumOfEdges + 4*NumOfFaces + 8*e + j; }
+      for (int n = 0; n < 64; n++)
+      {
+         const int l = pos1d[IJK[n][0]] + 4*(pos1d[IJK[n][1]] + 4*pos1d[IJK[n][2]]);
+         for (int c = 0; c < 3; c++) { xe[(size_t)192*e + l + 64*c] = val(dofs[n], c); }
+      }
+   }
+   const std::vector<real_t> equi = {0.0, 1.0/3.0, 2.0/3.0, 1.0};
+   SetNodesFromElementValues(3, Ordering::byVDIM, equi, xe);
 }
 
 void Mesh::Transform(std::function<void(const Vector &, Vector &)> f)

@@ -575,6 +575,8 @@ class Mesh
    void CheckElementOrientation();
    void Load(std::istream &input, int refine);
    void SetAttributes();
+   void SetNodesFromElementValues(int order, int ordering, const std::vector<real_t> &old_nodes, const std::vector<real_t> &xe_old);
+   void SetNodesFromLegacyCubic(const std::vector<real_t> &raw, int ordering);
    void Destroy();
    void Swap(Mesh &o);
    friend class FiniteElementSpace;

@@ -32,7 +32,8 @@ def parse_ex1(txt):
 
 # reference: BASELINE.md 2.1 (ex1 -pa -d cpu): unknowns, iterations, (Br,r)_0, (Br,r)_last
 EX1 = [("inline-hex.mesh", 3, 912673, 197, 1.84147e-05, 1.47345e-17),
-       ("toroid-hex.mesh", 3, 691488, 161, 6.14869e-05, 5.76421e-17)]
+       ("toroid-hex.mesh", 3, 691488, 161, 6.14869e-05, 5.76421e-17),
+       ("fichera-q3.mesh", 3, 802081, 364, 5.03701e-04, 4.96721e-16)]     # legacy "Cubic" nodes
 
 
 @pytest.mark.parametrize("mesh,order,unknowns,its,nom0,nom_last", EX1)
