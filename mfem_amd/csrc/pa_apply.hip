@@ -60,7 +60,15 @@ constexpr int minw_for(int KIND, int D, int PF = 0)
 #ifndef MFA_VGPR_CAP
 #define MFA_VGPR_CAP
 #endif
-template <int KIND, int D, int Q, int NBZ, bool GATHER, bool ACCUM, bool BLK = false, int ABL = 0, bool PERSIST = true, int PF = 0>
+// RB (register-blocked x / transposed-y / transposed-x contractions): instead of one output per
+// thread and sweep (one LDS read per FMA), a thread owns one LDS row -- (dy,dz) for the x
+// contractions, (qx,dz) for the transposed y contraction -- reads it once and produces every
+// output along the contracted direction from registers, with the basis factors as scalar
+// operands.  Same sums in the same order (bit-identical results), ~half the LDS traffic, which is
+// the busiest unit of the kernel at p >= 5 (profiles/r1/kbench_bp3_p5_pmc.txt: LDS active 59 %).
+// LDS rows are padded to an odd number of doubles so the row-per-thread accesses are
+// conflict-free.
+template <int KIND, int D, int Q, int NBZ, bool GATHER, bool ACCUM, bool BLK = false, int ABL = 0, bool PERSIST = true, int PF = 0, int RB = 0>
 __global__ void __launch_bounds__(Q*Q*NBZ, minw_for(KIND, D, PF)) MFA_VGPR_CAP
 k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const BasisT<D*Q> bg,
            const double *__restrict__ Dq, const double *__restrict__ x,
@@ -69,9 +77,19 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
    constexpr int NC = KIND ? 6 : 1;       // stored components per quadrature point
    constexpr int NF = KIND ? 3 : 1;       // fields carried through the z loop
    constexpr int NX = KIND ? 2 : 1;       // fields after the x contraction (B x, G x)
-   constexpr int D3 = D*D*D, DDQ = D*D*Q, DQQ = D*Q*Q, QQ = Q*Q;
+   // LDS strides (doubles): rows that one thread walks (sX, sBX/sGX, sV) are padded to an odd
+   // length; the (qy,qx) planes of sT keep dense rows and are padded as a whole so that the
+   // planes of consecutive dz start Q doubles apart modulo the bank period
+   constexpr int DP = RB ? (D | 1) : D, QP = RB ? (Q | 1) : Q;
+   constexpr int PLPAD = ((Q - Q*Q) % 32 + 32) % 32;
+   constexpr int QQ = Q*Q, PL = QQ + ((RB && PLPAD <= 8) ? PLPAD : 0);
+   constexpr int D3 = D*D*D, DDQ = D*D*QP, DQQ = D*PL;
    constexpr int Q3 = Q*Q*Q;
-   constexpr int SA = (D3 + NX*DDQ > NF*DQQ) ? D3 + NX*DDQ : NF*DQQ;
+   constexpr int SXN = D*D*DP;
+   // RB == 2: the x-contracted fields live in region V, so region A holds sX, then the
+   // y-contracted z-columns (sR), then sT
+   constexpr int SA1 = (RB == 2) ? SXN : SXN + NX*DDQ;
+   constexpr int SA = (SA1 > NF*DQQ) ? SA1 : NF*DQQ;
    constexpr int SV = NX*DDQ;
    constexpr int NXV = (D3 + QQ - 1)/QQ;  // x values staged per thread
    __shared__ double smem[NBZ][SA + SV];
@@ -93,9 +111,9 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
    if (b0 >= b1) { return; }              // uniform over the workgroup, before any barrier
 
    double *sA = smem[tz];
-   double *sX = sA, *sBX = sA + D3, *sGX = sBX + DDQ;   // phase 1 view of region A
-   double *sT = sA;                                     // phase 2 view of region A
    double *sV = sA + SA;
+   double *sX = sA, *sBX = (RB == 2) ? sV : sA + SXN, *sGX = sBX + DDQ;  // phase 1 view
+   double *sT = sA;                                     // phase 2 view of region A
 
    for (int i = t2 + QQ*tz; i < Q*D; i += QQ*NBZ)
    {
@@ -244,13 +262,13 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
       for (int k = 0; k < NXV; k++)
       {
          const int i = t2 + k*QQ;
-         if (i < D3) { sX[i] = xv[k]; }
+         if (i < D3) { sX[RB ? (i/D)*DP + i % D : i] = xv[k]; }
       }
       if (PERSIST) { load_gi(en); }       // next batch's gather indices: in flight from here
       __syncthreads();
       if (ABL & 1)
       {
-         double acc = sX[t2 % D3];
+         double acc = sX[t2 % D];
 #pragma unroll
          for (int qz = 0; qz < Q; qz++)
          {
@@ -284,8 +302,32 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
          continue;
       }
 
-      // --- x contraction: thread (qx = a, dy = b)
-      if (b < D)
+      // --- x contraction: thread (qx = a, dy = b); RB: thread t2 = row (dz,dy), all qx
+      int zofs, zx, zy, zt;
+      asm volatile("s_mov_b32 %0, 0" : "=s"(zx));
+      if (RB)
+      {
+         if (t2 < D*D)
+         {
+            double sx[D];
+#pragma unroll
+            for (int dx = 0; dx < D; dx++) { sx[dx] = sX[t2*DP + dx]; }
+#pragma unroll
+            for (int qx = 0; qx < Q; qx++)
+            {
+               double u = 0.0, v = 0.0;
+#pragma unroll
+               for (int dx = 0; dx < D; dx++)
+               {
+                  u += bg.b[qx*D + dx + zx]*sx[dx];
+                  if (KIND) { v += bg.g[qx*D + dx + zx]*sx[dx]; }
+               }
+               sBX[t2*QP + qx] = u;
+               if (KIND) { sGX[t2*QP + qx] = v; }
+            }
+         }
+      }
+      else if (b < D)
       {
          double Ba[D], Ga[D];
 #pragma unroll
@@ -297,18 +339,66 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
 #pragma unroll
             for (int dx = 0; dx < D; dx++)
             {
-               const double s = sX[(dz*D + b)*D + dx];
+               const double s = sX[(dz*D + b)*DP + dx];
                u += Ba[dx]*s;
                if (KIND) { v += Ga[dx]*s; }
             }
-            sBX[(dz*D + b)*Q + a] = u;
-            if (KIND) { sGX[(dz*D + b)*Q + a] = v; }
+            sBX[(dz*D + b)*QP + a] = u;
+            if (KIND) { sGX[(dz*D + b)*QP + a] = v; }
          }
       }
       __syncthreads();
 
       // --- y contraction into register z-columns: thread (qx = a, qy = b)
       double r1[D], r2[D], r3[D];
+      if (RB == 2)
+      {
+         // thread t2 = (qx, dz) reads its 2*D inputs once and produces the Q outputs along y
+         // into sR (the layout of sT); every thread then picks up its own z-column
+         int zr;
+         asm volatile("s_mov_b32 %0, 0" : "=s"(zr));
+         if (t2 < Q*D)
+         {
+            const int qx = t2 % Q, dz = t2 / Q;
+            double bx[D], gx[D];
+#pragma unroll
+            for (int dy = 0; dy < D; dy++)
+            {
+               bx[dy] = sBX[(dz*D + dy)*QP + qx];
+               gx[dy] = KIND ? sGX[(dz*D + dy)*QP + qx] : 0.0;
+            }
+#pragma unroll
+            for (int qy = 0; qy < Q; qy++)
+            {
+               double u = 0.0, v = 0.0, w = 0.0;
+#pragma unroll
+               for (int dy = 0; dy < D; dy++)
+               {
+                  w += bg.b[qy*D + dy + zr]*bx[dy];
+                  if (KIND)
+                  {
+                     u += bg.b[qy*D + dy + zr]*gx[dy];
+                     v += bg.g[qy*D + dy + zr]*bx[dy];
+                  }
+               }
+               sT[dz*PL + qy*Q + qx] = w;
+               if (KIND)
+               {
+                  sT[(D + dz)*PL + qy*Q + qx] = v;
+                  sT[(2*D + dz)*PL + qy*Q + qx] = u;
+               }
+            }
+         }
+         __syncthreads();
+#pragma unroll
+         for (int dz = 0; dz < D; dz++)
+         {
+            r3[dz] = sT[dz*PL + b*Q + a];
+            r2[dz] = KIND ? sT[(D + dz)*PL + b*Q + a] : 0.0;
+            r1[dz] = KIND ? sT[(2*D + dz)*PL + b*Q + a] : 0.0;
+         }
+      }
+      else
       {
          double Bb[D], Gb[D];
 #pragma unroll
@@ -320,11 +410,11 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
 #pragma unroll
             for (int dy = 0; dy < D; dy++)
             {
-               const double bx = sBX[(dz*D + dy)*Q + a];
+               const double bx = sBX[(dz*D + dy)*QP + a];
                w += Bb[dy]*bx;
                if (KIND)
                {
-                  const double gx = sGX[(dz*D + dy)*Q + a];
+                  const double gx = sGX[(dz*D + dy)*QP + a];
                   u += Bb[dy]*gx;
                   v += Gb[dy]*bx;
                }
@@ -338,7 +428,6 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
       // iteration (scalar loads, scalar cache): `zofs` is an opaque 0 that keeps the
       // compiler from hoisting all 2*Q*D of them out of the batch loop, where they would
       // not fit the SGPR file and spill to VGPR lanes.
-      int zofs;
       asm volatile("s_mov_b32 %0, 0" : "=s"(zofs));
       double t1[D], t2r[D], t3[D];
 #pragma unroll
@@ -387,15 +476,17 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
             for (int dz = 0; dz < D; dz++) { t3[dz] += bg.b[qz*D + dz + zofs]*u; }
          }
       }
-      __syncthreads();   // all reads of sBX/sGX done; region A is reused as sT
+      // all reads of sBX/sGX done; region A is reused as sT (RB == 2: every thread overwrites
+      // exactly the sR entries it read itself -- no barrier)
+      if (RB != 2) { __syncthreads(); }
 #pragma unroll
       for (int dz = 0; dz < D; dz++)
       {
-         sT[dz*QQ + b*Q + a] = t3[dz];
+         sT[dz*PL + b*Q + a] = t3[dz];
          if (KIND)
          {
-            sT[(D + dz)*QQ + b*Q + a] = t2r[dz];
-            sT[(2*D + dz)*QQ + b*Q + a] = t1[dz];
+            sT[(D + dz)*PL + b*Q + a] = t2r[dz];
+            sT[(2*D + dz)*PL + b*Q + a] = t1[dz];
          }
       }
       // --- next batch: x values first (needed first; vmcnt retires in order), then pa_data.
@@ -409,8 +500,42 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
       }
       __syncthreads();
 
-      // --- transposed y contraction: thread (qx = a, dy = b)
-      if (b < D)
+      // --- transposed y contraction: thread (qx = a, dy = b); RB: thread t2 = (qx, dz), all dy
+      asm volatile("s_mov_b32 %0, 0" : "=s"(zy));
+      if (RB)
+      {
+         if (t2 < Q*D)
+         {
+            const int qx = t2 % Q, dz = t2 / Q;
+            double v23[D], v1[D];
+#pragma unroll
+            for (int dy = 0; dy < D; dy++) { v23[dy] = 0.0; v1[dy] = 0.0; }
+#pragma unroll
+            for (int qy = 0; qy < Q; qy++)
+            {
+               const double T0 = sT[dz*PL + qy*Q + qx];
+               const double T1 = KIND ? sT[(D + dz)*PL + qy*Q + qx] : 0.0;
+               const double T2 = KIND ? sT[(2*D + dz)*PL + qy*Q + qx] : 0.0;
+#pragma unroll
+               for (int dy = 0; dy < D; dy++)
+               {
+                  v23[dy] += bg.b[qy*D + dy + zy]*T0;
+                  if (KIND)
+                  {
+                     v23[dy] += bg.g[qy*D + dy + zy]*T1;
+                     v1[dy] += bg.b[qy*D + dy + zy]*T2;
+                  }
+               }
+            }
+#pragma unroll
+            for (int dy = 0; dy < D; dy++)
+            {
+               sV[(dz*D + dy)*QP + qx] = v23[dy];
+               if (KIND) { sV[DDQ + (dz*D + dy)*QP + qx] = v1[dy]; }
+            }
+         }
+      }
+      else if (b < D)
       {
          double Bc[Q], Gc[Q];
 #pragma unroll
@@ -422,21 +547,67 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
 #pragma unroll
             for (int qy = 0; qy < Q; qy++)
             {
-               v23 += Bc[qy]*sT[dz*QQ + qy*Q + a];
+               v23 += Bc[qy]*sT[dz*PL + qy*Q + a];
                if (KIND)
                {
-                  v23 += Gc[qy]*sT[(D + dz)*QQ + qy*Q + a];
-                  v1 += Bc[qy]*sT[(2*D + dz)*QQ + qy*Q + a];
+                  v23 += Gc[qy]*sT[(D + dz)*PL + qy*Q + a];
+                  v1 += Bc[qy]*sT[(2*D + dz)*PL + qy*Q + a];
                }
             }
-            sV[(dz*D + b)*Q + a] = v23;
-            if (KIND) { sV[DDQ + (dz*D + b)*Q + a] = v1; }
+            sV[(dz*D + b)*QP + a] = v23;
+            if (KIND) { sV[DDQ + (dz*D + b)*QP + a] = v1; }
          }
       }
       __syncthreads();
 
-      // --- transposed x contraction and store: thread (dx = a, dy = b)
-      if (a < D && b < D && active)
+      // --- transposed x contraction and store: thread (dx = a, dy = b); RB: thread t2 = row
+      // (dz,dy), all dx -- D consecutive doubles of yE per thread
+      asm volatile("s_mov_b32 %0, 0" : "=s"(zt));
+      if (RB)
+      {
+         if (t2 < D*D && active)
+         {
+            double V23[Q], V1[Q];
+#pragma unroll
+            for (int qx = 0; qx < Q; qx++) { V23[qx] = sV[t2*QP + qx]; V1[qx] = KIND ? sV[DDQ + t2*QP + qx] : 0.0; }
+            double yv[D];
+#pragma unroll
+            for (int dx = 0; dx < D; dx++)
+            {
+               double y = 0.0;
+#pragma unroll
+               for (int qx = 0; qx < Q; qx++)
+               {
+                  y += bg.b[qx*D + dx + zt]*V23[qx];
+                  if (KIND) { y += bg.g[qx*D + dx + zt]*V1[qx]; }
+               }
+               yv[dx] = y;
+            }
+            double *ye = yE + e*D3 + t2*D;
+            if (D % 2 == 0)
+            {
+               double2 *ye2 = reinterpret_cast<double2*>(ye);      // e*D3 + t2*D is even: 16-B aligned
+#pragma unroll
+               for (int dx = 0; dx < D/2; dx++)
+               {
+                  double2 o;
+                  if (ACCUM) { o = ye2[dx]; o.x += yv[2*dx]; o.y += yv[2*dx + 1]; }
+                  else { o.x = yv[2*dx]; o.y = yv[2*dx + 1]; }
+                  ye2[dx] = o;
+               }
+            }
+            else
+            {
+#pragma unroll
+               for (int dx = 0; dx < D; dx++)
+               {
+                  if (ACCUM) { ye[dx] += yv[dx]; }
+                  else { ye[dx] = yv[dx]; }
+               }
+            }
+         }
+      }
+      else if (a < D && b < D && active)
       {
          double Bc[Q], Gc[Q];
 #pragma unroll
@@ -449,8 +620,8 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
 #pragma unroll
             for (int qx = 0; qx < Q; qx++)
             {
-               y += Bc[qx]*sV[(dz*D + b)*Q + qx];
-               if (KIND) { y += Gc[qx]*sV[DDQ + (dz*D + b)*Q + qx]; }
+               y += Bc[qx]*sV[(dz*D + b)*QP + qx];
+               if (KIND) { y += Gc[qx]*sV[DDQ + (dz*D + b)*QP + qx]; }
             }
             if (ACCUM) { ye[dz*D*D] += y; }
             else { ye[dz*D*D] = y; }
@@ -661,32 +832,54 @@ static int apply_pf(int KIND, int D, int Q)
    }
    if (forced >= 0) { return forced; }
    // measured (profiles/r1/sweep_pf_*.txt): streaming pays where the whole-column prefetch costs
-   // a wave of occupancy -- diffusion at p = 8 (501 -> 351 us at 1e7 dofs), and the collocated
-   // (Q = D) kernels at p = 5, 7, 8; everywhere else holding the column is as fast or faster
+   // a wave of occupancy -- diffusion at p = 7, 8 (p = 8: 501 -> 351 us at 1e7 dofs), and the
+   // collocated (Q = D) kernels at p = 5, 7, 8; everywhere else holding the column is as fast or faster
    if (KIND == 1)
    {
       if (D >= 9) { return Q == D ? 3 : 2; }
-      if (D == 8 && Q == 8) { return 2; }
+      if (D == 8) { return 2; }
       if (D == 6 && Q == 6) { return 3; }
    }
    return 0;
 }
 
-template <int KIND, int D, int Q, bool GATHER, bool ACCUM, bool BLK, int PF = 0>
+// register-blocked contractions (kernel comment): MFEM_AMD_APPLY_RB=0|1 overrides (tuning aid)
+static int apply_rb(int KIND, int D, int Q)
+{
+   static int forced = -2;
+   if (forced == -2)
+   {
+      const char *v = getenv("MFEM_AMD_APPLY_RB");
+      forced = (v && *v >= '0' && *v <= '2') ? (*v - '0') : -1;
+   }
+   if (forced >= 0) { return forced; }
+   // measured (profiles/r1/sweep_rb_*.txt): level 1 pays from p = 3 on; level 2 adds a little for
+   // mass and for the largest elements, where its smaller register footprint matters
+   if (KIND == 0) { return D >= 4 ? 2 : 1; }
+   if (Q == D) { return (D == 5 || D == 6 || D >= 8) ? 2 : 1; }
+   return D >= 8 ? 2 : (D >= 4 ? 1 : 0);
+}
+
+template <int KIND, int D, int Q, bool GATHER, bool ACCUM, bool BLK, int PF = 0, int RB = 0, bool RESOLVED = false>
 static int launch_apply(int64_t ne, const double *B, const double *G, const double *Dq,
                         const double *x, const int *gmap, double *yE, hipStream_t s)
 {
    constexpr int NBZ = nbz_for(Q);
-   if (BLK && GATHER && !ACCUM && PF == 0 && Q > 3)
+   constexpr bool HOT = BLK && GATHER && !ACCUM && Q > 3;
+   if (HOT && !RESOLVED)
    {
-      // the hot path has streamed variants
+      // the hot path has streamed and register-blocked variants
       const int pf = apply_pf(KIND, D, Q);
-      if (pf == 2) { return launch_apply<KIND, D, Q, GATHER, ACCUM, BLK, (BLK && GATHER && !ACCUM && Q > 3) ? 2 : 0>(ne, B, G, Dq, x, gmap, yE, s); }
-      if (pf == 3) { return launch_apply<KIND, D, Q, GATHER, ACCUM, BLK, (BLK && GATHER && !ACCUM && Q > 3) ? 3 : 0>(ne, B, G, Dq, x, gmap, yE, s); }
+      const int rb = apply_rb(KIND, D, Q);
+#define MFA_VARIANT(P, R) \
+      if (pf == P && rb == R) { return launch_apply<KIND, D, Q, GATHER, ACCUM, BLK, HOT ? P : 0, HOT ? R : 0, true>(ne, B, G, Dq, x, gmap, yE, s); }
+      MFA_VARIANT(0, 1) MFA_VARIANT(2, 0) MFA_VARIANT(2, 1) MFA_VARIANT(3, 0) MFA_VARIANT(3, 1)
+      MFA_VARIANT(0, 2) MFA_VARIANT(2, 2) MFA_VARIANT(3, 2)
+#undef MFA_VARIANT
    }
    const int mode = apply_mode(KIND, D, Q);   // 0 one batch per workgroup, 1 persistent/contiguous, 2 persistent/round-robin
-   auto kern = k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM, BLK, 0, true, PF>;
-   auto kern1 = k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM, BLK, 0, false, PF>;
+   auto kern = k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM, BLK, 0, true, PF, RB>;
+   auto kern1 = k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM, BLK, 0, false, PF, RB>;
    // resident workgroups on the current device (queried once per instantiation and device)
    static int resident[64] = {0};
    int dev = 0;

@@ -55,6 +55,9 @@ def run(problem, p, n, steps, which, layout=1):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1)*1e-3/k
 
+    import os
+    if os.environ.get("KBENCH_PTRS"):
+        print("   ptrs pa=%x x=%x yE=%x gm=%x" % (pa.data_ptr(), x.data_ptr(), yE.data_ptr(), gm.data_ptr()), flush=True)
     b1, b2 = bench.algorithmic_bytes(kind, D, Q, ne, ndofs)
     t1 = timed(l2e, steps) if which in ("both", "l2e") else float("nan")
     t2 = timed(e2l, steps) if which in ("both", "e2l") else float("nan")
