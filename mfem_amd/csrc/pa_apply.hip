@@ -78,11 +78,14 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
    constexpr int NF = KIND ? 3 : 1;       // fields carried through the z loop
    constexpr int NX = KIND ? 2 : 1;       // fields after the x contraction (B x, G x)
    // LDS strides (doubles): rows that one thread walks (sX, sBX/sGX, sV) are padded to an odd
-   // length; the (qy,qx) planes of sT keep dense rows and are padded as a whole so that the
-   // planes of consecutive dz start Q doubles apart modulo the bank period
+   // length; the (qy,qx) planes of sT keep dense rows and get a small pad as a whole for even Q.
+   // (Measured: padding or transposing the planes so that the row-per-thread reads are entirely
+   // conflict-free -- they cost 20 % conflict cycles at p = 5, profiles/r1/kbench_bp3_p5_rb_pmc.txt
+   // -- is no faster, and at p = 4 the extra LDS costs a resident workgroup: 347 -> 382 us.)
    constexpr int DP = RB ? (D | 1) : D, QP = RB ? (Q | 1) : Q;
    constexpr int PLPAD = ((Q - Q*Q) % 32 + 32) % 32;
    constexpr int QQ = Q*Q, PL = QQ + ((RB && PLPAD <= 8) ? PLPAD : 0);
+   auto tix = [](const int plane, const int qy, const int qx) { return plane*PL + qy*Q + qx; };
    constexpr int D3 = D*D*D, DDQ = D*D*QP, DQQ = D*PL;
    constexpr int Q3 = Q*Q*Q;
    constexpr int SXN = D*D*DP;
@@ -381,11 +384,11 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
                      v += bg.g[qy*D + dy + zr]*bx[dy];
                   }
                }
-               sT[dz*PL + qy*Q + qx] = w;
+               sT[tix(dz, qy, qx)] = w;
                if (KIND)
                {
-                  sT[(D + dz)*PL + qy*Q + qx] = v;
-                  sT[(2*D + dz)*PL + qy*Q + qx] = u;
+                  sT[tix(D + dz, qy, qx)] = v;
+                  sT[tix(2*D + dz, qy, qx)] = u;
                }
             }
          }
@@ -393,9 +396,9 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
 #pragma unroll
          for (int dz = 0; dz < D; dz++)
          {
-            r3[dz] = sT[dz*PL + b*Q + a];
-            r2[dz] = KIND ? sT[(D + dz)*PL + b*Q + a] : 0.0;
-            r1[dz] = KIND ? sT[(2*D + dz)*PL + b*Q + a] : 0.0;
+            r3[dz] = sT[tix(dz, b, a)];
+            r2[dz] = KIND ? sT[tix(D + dz, b, a)] : 0.0;
+            r1[dz] = KIND ? sT[tix(2*D + dz, b, a)] : 0.0;
          }
       }
       else
@@ -482,11 +485,11 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
 #pragma unroll
       for (int dz = 0; dz < D; dz++)
       {
-         sT[dz*PL + b*Q + a] = t3[dz];
+         sT[tix(dz, b, a)] = t3[dz];
          if (KIND)
          {
-            sT[(D + dz)*PL + b*Q + a] = t2r[dz];
-            sT[(2*D + dz)*PL + b*Q + a] = t1[dz];
+            sT[tix(D + dz, b, a)] = t2r[dz];
+            sT[tix(2*D + dz, b, a)] = t1[dz];
          }
       }
       // --- next batch: x values first (needed first; vmcnt retires in order), then pa_data.
@@ -513,9 +516,9 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
 #pragma unroll
             for (int qy = 0; qy < Q; qy++)
             {
-               const double T0 = sT[dz*PL + qy*Q + qx];
-               const double T1 = KIND ? sT[(D + dz)*PL + qy*Q + qx] : 0.0;
-               const double T2 = KIND ? sT[(2*D + dz)*PL + qy*Q + qx] : 0.0;
+               const double T0 = sT[tix(dz, qy, qx)];
+               const double T1 = KIND ? sT[tix(D + dz, qy, qx)] : 0.0;
+               const double T2 = KIND ? sT[tix(2*D + dz, qy, qx)] : 0.0;
 #pragma unroll
                for (int dy = 0; dy < D; dy++)
                {
@@ -547,11 +550,11 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
 #pragma unroll
             for (int qy = 0; qy < Q; qy++)
             {
-               v23 += Bc[qy]*sT[dz*PL + qy*Q + a];
+               v23 += Bc[qy]*sT[tix(dz, qy, a)];
                if (KIND)
                {
-                  v23 += Gc[qy]*sT[(D + dz)*PL + qy*Q + a];
-                  v1 += Bc[qy]*sT[(2*D + dz)*PL + qy*Q + a];
+                  v23 += Gc[qy]*sT[tix(D + dz, qy, a)];
+                  v1 += Bc[qy]*sT[tix(2*D + dz, qy, a)];
                }
             }
             sV[(dz*D + b)*QP + a] = v23;
