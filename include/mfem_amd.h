@@ -193,6 +193,44 @@ int mfem_amd_jacobi_apply(int64_t n, const double *dinv, const double *r, double
 
 /* ---- Jacobi-PCG on the PA operator, scalars resident on the device ---------------- */
 
+/* ---- vector H1 spaces (vdim components of one scalar space) ------------------------------ */
+
+/* ElementRestriction::MultTranspose / AddMultTranspose / AbsMultTranspose for vdim > 1
+ * (fem/restriction.cpp:152-180,196-221): y[vdof(i,c)] (+)= sum_j xE[(idx_j % nd) +
+ * nd*(c + vdim*(idx_j / nd))], same order as the scalar rows.  nd = D1D^3.  byvdim as
+ * Ordering::byVDIM (fem/fespace.hpp). */
+int mfem_amd_restrict_scatter_vdim(int64_t ndofs, int nd, int vdim, int byvdim, const int *offsets,
+                                   const int *indices, const double *xE, double *y, int add,
+                                   int absv, void *stream);
+
+/* Fused ElementRestriction::Mult + VectorDiffusionIntegrator / VectorMassIntegrator::AddMultPA
+ * (fem/integ/bilininteg_vecdiffusion_pa.hpp:108-170, bilininteg_vecmass_pa.hpp; kind as
+ * mfem_amd_pa_apply_L2E): yE(D,D,D,vdim,NE) = A_c x_c for every component c, x an L-vector of
+ * vdim*ndofs entries.  D: the SCALAR integrator's pa_data (d_comp_stride = 0: scalar coefficient,
+ * read once for all components -- the reference stores and reads vdim identical copies), or one
+ * array per component d_comp_stride doubles apart (vector coefficient; pa_layout 0 then means
+ * the reference's (Q^3,NC,vdim,NE)).  ess_marker: optional vdim*ndofs bytes, nonzero entries of
+ * x read as 0 (ConstrainedOperator z[ess] = 0, linalg/operator.cpp:604-612). */
+int mfem_amd_pa_apply_L2E_vdim(int kind, int pa_layout, int D1D, int Q1D, int64_t ne, int vdim,
+                               int byvdim, int64_t ndofs, const double *B, const double *G,
+                               const double *D, int64_t d_comp_stride, const int *gather_map,
+                               const unsigned char *ess_marker, const double *x, double *yE,
+                               void *stream);
+
+/* VectorDiffusionIntegrator::AddMultPA at the dispatch-table seam
+ * (ApplyKernelType, fem/bilininteg.hpp; SmemPAVectorDiffusionApply3D,
+ * fem/integ/bilininteg_vecdiffusion_pa.hpp:108-170): yE += A xE on (D,D,D,vdim,NE) E-vectors;
+ * D is the reference's pa_data (Q,Q,Q,6,vdim,NE) (bilininteg_vecdiffusion_pa.cpp:228-290).
+ * coeff_vdim 1 or vdim; matrix coefficients (vdim^2) are rejected. */
+int mfem_amd_pa_vector_diffusion_apply_3d(int D1D, int Q1D, int64_t ne, int vdim, int coeff_vdim,
+                                          const double *B, const double *G, const double *D,
+                                          const double *xE, double *yE, void *stream);
+/* VectorMassIntegrator::AddMultPA (fem/integ/bilininteg_vecmass_pa.hpp): D is (Q,Q,Q,coeff_vdim,NE)
+ * (bilininteg_vecmass_pa.cpp:118-160). */
+int mfem_amd_pa_vector_mass_apply_3d(int D1D, int Q1D, int64_t ne, int vdim, int coeff_vdim,
+                                     const double *B, const double *D, const double *xE,
+                                     double *yE, void *stream);
+
 /* Problem description for mfem_amd_pcg_pa (all device pointers unless marked HOST). */
 typedef struct mfem_amd_pa_operator
 {
@@ -208,7 +246,15 @@ typedef struct mfem_amd_pa_operator
    int64_t ness;
    const int *ess;           /* constraint_list */
    const unsigned char *ess_marker; /* ndofs bytes: 1 essential, 2 essential ghost copy (multi-GPU) */
-   double *yE;               /* work: NE*D1D^3 doubles */
+   double *yE;               /* work: NE*D1D^3 doubles (times vdim for a vector space) */
+   /* Vector H1 spaces (VectorMassIntegrator / VectorDiffusionIntegrator; BP2/BP4/BP6).  Zero =
+    * scalar space, the fields above mean what they always did.  With vdim >= 1 set: vectors
+    * have vdim*ndofs entries ordered byNODES (byvdim = 0) or byVDIM (1); gather_map / offsets /
+    * indices stay the scalar space's tables; ess / ess_marker index vdofs (ess_marker: vdim*ndofs
+    * bytes) and masked_gather_map is not used (the marker is applied in the gather). */
+   int vdim, byvdim;
+   int64_t pa_comp_stride;   /* 0: one pa_data shared by all components (scalar coefficient);
+                                else doubles between the components' pa_data arrays */
 } mfem_amd_pa_operator;
 
 /* ConstrainedOperator(PABilinearFormExtension)::Mult, DIAG_ONE

@@ -32,7 +32,8 @@ class PaOperator(C.Structure):
     _fields_ = [("kind", cint), ("pa_layout", cint), ("D1D", cint), ("Q1D", cint), ("ne", i64), ("ndofs", i64),
                 ("B", vp), ("G", vp), ("pa_data", vp), ("gather_map", vp),
                 ("masked_gather_map", vp), ("offsets", vp), ("indices", vp),
-                ("ness", i64), ("ess", vp), ("ess_marker", vp), ("yE", vp)]
+                ("ness", i64), ("ess", vp), ("ess_marker", vp), ("yE", vp),
+                ("vdim", cint), ("byvdim", cint), ("pa_comp_stride", i64)]
 
 
 AR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
@@ -71,6 +72,10 @@ _SIGS = {
     "mfem_amd_pa_diffusion_diag_3d": (cint, [cint, cint, i64, cint, _hd, _hd, vp, cint, vp, vp]),
     "mfem_amd_pa_mass_diag_3d": (cint, [cint, cint, i64, _hd, vp, cint, vp, vp]),
     "mfem_amd_pa_apply_L2E": (cint, [cint, cint, cint, cint, i64, _hd, _hd, vp, vp, vp, vp, vp]),
+    "mfem_amd_restrict_scatter_vdim": (cint, [i64, cint, cint, cint, vp, vp, vp, vp, cint, cint, vp]),
+    "mfem_amd_pa_apply_L2E_vdim": (cint, [cint, cint, cint, cint, i64, cint, cint, i64, _hd, _hd, vp, i64, vp, vp, vp, vp, vp]),
+    "mfem_amd_pa_vector_diffusion_apply_3d": (cint, [cint, cint, i64, cint, cint, _hd, _hd, vp, vp, vp, vp]),
+    "mfem_amd_pa_vector_mass_apply_3d": (cint, [cint, cint, i64, cint, cint, _hd, vp, vp, vp, vp]),
     "mfem_amd_set_marker": (cint, [i64, vp, vp, vp]),
     "mfem_amd_mask_gather_map": (cint, [i64, vp, vp, vp, vp]),
     "mfem_amd_set_subvector": (cint, [i64, vp, vp, dbl, vp, vp]),

@@ -89,6 +89,17 @@ __device__ __forceinline__ double wave_sum(double v)
    return v;
 }
 
+// Vector H1 spaces: arguments of the component loop of k_pa_apply (pa_apply.hip)
+struct VecArgs
+{
+   int vd;                        // components
+   int byvdim;                    // L-vector ordering: 0 byNODES (x[c*ndofs + i]), 1 byVDIM (x[i*vd + c])
+   int64_t ndofs;                 // scalar L-dofs
+   const unsigned char *marker;   // optional, vd*ndofs bytes indexed like x: nonzero reads as 0.0 (essential dofs)
+   int64_t d_comp_stride;         // 0: every component uses the same pa_data; else blocked layout: doubles between
+                                  // the components' arrays; MFEM layout: nonzero = (Q^3,NC,vd,NE) as the reference
+};
+
 // Workgroup sum for blockDim.x == 256 (4 waves); result valid in thread 0.
 // Fixed tree: lanes by shuffle, then waves 0..3 added in order.
 __device__ __forceinline__ double block_sum_256(double v, double *s4)

@@ -68,12 +68,20 @@ constexpr int minw_for(int KIND, int D, int PF = 0)
 // the busiest unit of the kernel at p >= 5 (profiles/r1/kbench_bp3_p5_pmc.txt: LDS active 59 %).
 // LDS rows are padded to an odd number of doubles so the row-per-thread accesses are
 // conflict-free.
-template <int KIND, int D, int Q, int NBZ, bool GATHER, bool ACCUM, bool BLK = false, int ABL = 0, bool PERSIST = true, int PF = 0, int RB = 0>
+//
+// VEC (vector H1 spaces, VectorMassIntegrator / VectorDiffusionIntegrator with a scalar or vector
+// coefficient: fem/integ/bilininteg_vecdiffusion_pa.hpp:108-170 applies the scalar operator to
+// every component): the workgroup loops over the vd components of its elements with the gather
+// indices -- and, when all components share one pa_data (scalar coefficient), the pa_data
+// columns -- held in registers: pa_data is read once for vd components, where the reference
+// stores and reads vd identical copies.  E-vectors are (D,D,D,vd,NE) as in the reference.
+template <int KIND, int D, int Q, int NBZ, bool GATHER, bool ACCUM, bool BLK = false, int ABL = 0, bool PERSIST = true, int PF = 0, int RB = 0, bool VEC = false>
 __global__ void __launch_bounds__(Q*Q*NBZ, minw_for(KIND, D, PF)) MFA_VGPR_CAP
 k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const BasisT<D*Q> bg,
            const double *__restrict__ Dq, const double *__restrict__ x,
-           const int *__restrict__ gmap, double *__restrict__ yE)
+           const int *__restrict__ gmap, double *__restrict__ yE, const VecArgs va)
 {
+   static_assert(!VEC || (!PERSIST && PF == 0 && ABL == 0), "the component loop runs in the one-batch-per-workgroup schedule");
    constexpr int NC = KIND ? 6 : 1;       // stored components per quadrature point
    constexpr int NF = KIND ? 3 : 1;       // fields carried through the z loop
    constexpr int NX = KIND ? 2 : 1;       // fields after the x contraction (B x, G x)
@@ -129,6 +137,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
    double On[PF > 0 ? PF : 1][NC];        // first PF slices of the next batch (persistent schedule)
    double xv[NXV];
    int gi[NXV];
+   int comp = 0;                          // VEC: component being worked on
 
    // ---- loaders (plain loads into registers; they survive the barriers) ----
    // Every load is unconditional: out-of-range threads / elements read a clamped, valid
@@ -163,12 +172,21 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
          for (int k = 0; k < NXV; k++) { xv[k] = 1.0; }
          return;
       }
-      const double *xe = x + (e < elast ? e : elast)*D3;
+      const int64_t ec = e < elast ? e : elast;
+      const double *xe = x + (VEC ? ec*va.vd + comp : ec)*D3;
 #pragma unroll
       for (int k = 0; k < NXV; k++)
       {
          const int i = t2 + k*QQ;
-         if (GATHER)
+         if (GATHER && VEC)
+         {
+            const int64_t g = gi[k] >= 0 ? gi[k] : 0;
+            const int64_t idx = va.byvdim ? g*va.vd + comp : g + comp*va.ndofs;
+            const double v = x[idx];
+            const bool masked = va.marker ? (va.marker[idx] != 0) : false;
+            xv[k] = (gi[k] >= 0 && !masked) ? v : 0.0;
+         }
+         else if (GATHER)
          {
             const double v = x[gi[k] >= 0 ? gi[k] : 0];
             xv[k] = gi[k] >= 0 ? v : 0.0;
@@ -193,7 +211,8 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
          // blocked layout (common.h): whole-workgroup contiguous runs, 16 B per lane
          if (KIND)
          {
-            const double2 *Db = reinterpret_cast<const double2*>(Dq) + bt*(int64_t)(3*Q*NBZ*QQ) + tz*QQ + b*Q + a;
+            const double2 *Db = reinterpret_cast<const double2*>(Dq + (VEC ? comp*va.d_comp_stride : 0))
+                                + bt*(int64_t)(3*Q*NBZ*QQ) + tz*QQ + b*Q + a;
 #pragma unroll
             for (int qz = 0; qz < Q; qz++)
             {
@@ -207,13 +226,15 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
          }
          else
          {
-            const double *Db = Dq + bt*(int64_t)(Q*NBZ*QQ) + tz*QQ + b*Q + a;
+            const double *Db = Dq + (VEC ? comp*va.d_comp_stride : 0) + bt*(int64_t)(Q*NBZ*QQ) + tz*QQ + b*Q + a;
 #pragma unroll
             for (int qz = 0; qz < Q; qz++) { O[qz][0] = Db[qz*(NBZ*QQ)]; }
          }
          return;
       }
-      const double *De = Dq + (e < elast ? e : elast)*(int64_t)(NC*Q3) + b*Q + a;
+      const int64_t ec = e < elast ? e : elast;
+      const int64_t blk = (VEC && va.d_comp_stride) ? ec*va.vd + comp : ec;   // (Q^3,NC,vd,NE) or (Q^3,NC,NE)
+      const double *De = Dq + blk*(int64_t)(NC*Q3) + b*Q + a;
 #pragma unroll
       for (int qz = 0; qz < Q; qz++)
       {
@@ -260,379 +281,387 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
       // the batch loop and held in ~90 VGPRs for the whole kernel
       int vz;
       asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+      for (comp = 0; comp < (VEC ? va.vd : 1); comp++)
+      {
+         if (VEC && comp > 0)
+         {
+            load_xv(e);
+            if (va.d_comp_stride) { load_O(e, bt); }
+         }
 
 #pragma unroll
-      for (int k = 0; k < NXV; k++)
-      {
-         const int i = t2 + k*QQ;
-         if (i < D3) { sX[RB ? (i/D)*DP + i % D : i] = xv[k]; }
-      }
-      if (PERSIST) { load_gi(en); }       // next batch's gather indices: in flight from here
-      __syncthreads();
-      if (ABL & 1)
-      {
-         double acc = sX[t2 % D];
-#pragma unroll
-         for (int qz = 0; qz < Q; qz++)
+         for (int k = 0; k < NXV; k++)
          {
-#pragma unroll
-            for (int c = 0; c < NC; c++) { acc += O[qz][c]; }
+            const int i = t2 + k*QQ;
+            if (i < D3) { sX[RB ? (i/D)*DP + i % D : i] = xv[k]; }
          }
-         __builtin_amdgcn_sched_barrier(0);
-         load_xv(en);
-         load_O(en, btn);
-         if (ABL & 16)
+         if (PERSIST) { load_gi(en); }       // next batch's gather indices: in flight from here
+         __syncthreads();
+         if (ABL & 1)
          {
-            const int tid = t2 + QQ*tz;
-            const int nst = (ABL & 128) ? 64 : QQ*NBZ;   // 128: only wave 0 stores
-            if (tid < nst)
-            for (int i = tid; i < NBZ*D3; i += nst)
+            double acc = sX[t2 % D];
+#pragma unroll
+            for (int qz = 0; qz < Q; qz++)
             {
-               if (bt*NBZ*D3 + i < ne*D3)
+#pragma unroll
+               for (int c = 0; c < NC; c++) { acc += O[qz][c]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_xv(en);
+            load_O(en, btn);
+            if (ABL & 16)
+            {
+               const int tid = t2 + QQ*tz;
+               const int nst = (ABL & 128) ? 64 : QQ*NBZ;   // 128: only wave 0 stores
+               if (tid < nst)
+               for (int i = tid; i < NBZ*D3; i += nst)
                {
-                  if (ABL & 32) { __builtin_nontemporal_store(acc, &yE[bt*NBZ*D3 + i]); }
-                  else if (ABL & 64) { yE[(blockIdx.x*NBZ*D3 + i) % (ne*D3)] = acc; }
-                  else { yE[bt*NBZ*D3 + i] = acc; }
+                  if (bt*NBZ*D3 + i < ne*D3)
+                  {
+                     if (ABL & 32) { __builtin_nontemporal_store(acc, &yE[bt*NBZ*D3 + i]); }
+                     else if (ABL & 64) { yE[(blockIdx.x*NBZ*D3 + i) % (ne*D3)] = acc; }
+                     else { yE[bt*NBZ*D3 + i] = acc; }
+                  }
+               }
+            }
+            else if (active && !(ABL & 4))
+            {
+               for (int i = t2; i < D3; i += QQ) { yE[e*D3 + i] = acc; }
+            }
+            if ((ABL & 4) && acc == 1.2345e-300) { yE[0] = acc; }
+            __syncthreads();
+            continue;
+         }
+
+         // --- x contraction: thread (qx = a, dy = b); RB: thread t2 = row (dz,dy), all qx
+         int zofs, zx, zy, zt;
+         asm volatile("s_mov_b32 %0, 0" : "=s"(zx));
+         if (RB)
+         {
+            if (t2 < D*D)
+            {
+               double sx[D];
+#pragma unroll
+               for (int dx = 0; dx < D; dx++) { sx[dx] = sX[t2*DP + dx]; }
+#pragma unroll
+               for (int qx = 0; qx < Q; qx++)
+               {
+                  double u = 0.0, v = 0.0;
+#pragma unroll
+                  for (int dx = 0; dx < D; dx++)
+                  {
+                     u += bg.b[qx*D + dx + zx]*sx[dx];
+                     if (KIND) { v += bg.g[qx*D + dx + zx]*sx[dx]; }
+                  }
+                  sBX[t2*QP + qx] = u;
+                  if (KIND) { sGX[t2*QP + qx] = v; }
                }
             }
          }
-         else if (active && !(ABL & 4))
+         else if (b < D)
          {
-            for (int i = t2; i < D3; i += QQ) { yE[e*D3 + i] = acc; }
-         }
-         if ((ABL & 4) && acc == 1.2345e-300) { yE[0] = acc; }
-         __syncthreads();
-         continue;
-      }
-
-      // --- x contraction: thread (qx = a, dy = b); RB: thread t2 = row (dz,dy), all qx
-      int zofs, zx, zy, zt;
-      asm volatile("s_mov_b32 %0, 0" : "=s"(zx));
-      if (RB)
-      {
-         if (t2 < D*D)
-         {
-            double sx[D];
+            double Ba[D], Ga[D];
 #pragma unroll
-            for (int dx = 0; dx < D; dx++) { sx[dx] = sX[t2*DP + dx]; }
+            for (int dx = 0; dx < D; dx++) { Ba[dx] = sB[a*D + dx + vz]; Ga[dx] = KIND ? sG[a*D + dx + vz] : 0.0; }
 #pragma unroll
-            for (int qx = 0; qx < Q; qx++)
+            for (int dz = 0; dz < D; dz++)
             {
                double u = 0.0, v = 0.0;
 #pragma unroll
                for (int dx = 0; dx < D; dx++)
                {
-                  u += bg.b[qx*D + dx + zx]*sx[dx];
-                  if (KIND) { v += bg.g[qx*D + dx + zx]*sx[dx]; }
+                  const double s = sX[(dz*D + b)*DP + dx];
+                  u += Ba[dx]*s;
+                  if (KIND) { v += Ga[dx]*s; }
                }
-               sBX[t2*QP + qx] = u;
-               if (KIND) { sGX[t2*QP + qx] = v; }
+               sBX[(dz*D + b)*QP + a] = u;
+               if (KIND) { sGX[(dz*D + b)*QP + a] = v; }
             }
          }
-      }
-      else if (b < D)
-      {
-         double Ba[D], Ga[D];
-#pragma unroll
-         for (int dx = 0; dx < D; dx++) { Ba[dx] = sB[a*D + dx + vz]; Ga[dx] = KIND ? sG[a*D + dx + vz] : 0.0; }
-#pragma unroll
-         for (int dz = 0; dz < D; dz++)
-         {
-            double u = 0.0, v = 0.0;
-#pragma unroll
-            for (int dx = 0; dx < D; dx++)
-            {
-               const double s = sX[(dz*D + b)*DP + dx];
-               u += Ba[dx]*s;
-               if (KIND) { v += Ga[dx]*s; }
-            }
-            sBX[(dz*D + b)*QP + a] = u;
-            if (KIND) { sGX[(dz*D + b)*QP + a] = v; }
-         }
-      }
-      __syncthreads();
+         __syncthreads();
 
-      // --- y contraction into register z-columns: thread (qx = a, qy = b)
-      double r1[D], r2[D], r3[D];
-      if (RB == 2)
-      {
-         // thread t2 = (qx, dz) reads its 2*D inputs once and produces the Q outputs along y
-         // into sR (the layout of sT); every thread then picks up its own z-column
-         int zr;
-         asm volatile("s_mov_b32 %0, 0" : "=s"(zr));
-         if (t2 < Q*D)
+         // --- y contraction into register z-columns: thread (qx = a, qy = b)
+         double r1[D], r2[D], r3[D];
+         if (RB == 2)
          {
-            const int qx = t2 % Q, dz = t2 / Q;
-            double bx[D], gx[D];
-#pragma unroll
-            for (int dy = 0; dy < D; dy++)
+            // thread t2 = (qx, dz) reads its 2*D inputs once and produces the Q outputs along y
+            // into sR (the layout of sT); every thread then picks up its own z-column
+            int zr;
+            asm volatile("s_mov_b32 %0, 0" : "=s"(zr));
+            if (t2 < Q*D)
             {
-               bx[dy] = sBX[(dz*D + dy)*QP + qx];
-               gx[dy] = KIND ? sGX[(dz*D + dy)*QP + qx] : 0.0;
-            }
+               const int qx = t2 % Q, dz = t2 / Q;
+               double bx[D], gx[D];
 #pragma unroll
-            for (int qy = 0; qy < Q; qy++)
+               for (int dy = 0; dy < D; dy++)
+               {
+                  bx[dy] = sBX[(dz*D + dy)*QP + qx];
+                  gx[dy] = KIND ? sGX[(dz*D + dy)*QP + qx] : 0.0;
+               }
+#pragma unroll
+               for (int qy = 0; qy < Q; qy++)
+               {
+                  double u = 0.0, v = 0.0, w = 0.0;
+#pragma unroll
+                  for (int dy = 0; dy < D; dy++)
+                  {
+                     w += bg.b[qy*D + dy + zr]*bx[dy];
+                     if (KIND)
+                     {
+                        u += bg.b[qy*D + dy + zr]*gx[dy];
+                        v += bg.g[qy*D + dy + zr]*bx[dy];
+                     }
+                  }
+                  sT[tix(dz, qy, qx)] = w;
+                  if (KIND)
+                  {
+                     sT[tix(D + dz, qy, qx)] = v;
+                     sT[tix(2*D + dz, qy, qx)] = u;
+                  }
+               }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int dz = 0; dz < D; dz++)
+            {
+               r3[dz] = sT[tix(dz, b, a)];
+               r2[dz] = KIND ? sT[tix(D + dz, b, a)] : 0.0;
+               r1[dz] = KIND ? sT[tix(2*D + dz, b, a)] : 0.0;
+            }
+         }
+         else
+         {
+            double Bb[D], Gb[D];
+#pragma unroll
+            for (int dy = 0; dy < D; dy++) { Bb[dy] = sB[b*D + dy + vz]; Gb[dy] = KIND ? sG[b*D + dy + vz] : 0.0; }
+#pragma unroll
+            for (int dz = 0; dz < D; dz++)
             {
                double u = 0.0, v = 0.0, w = 0.0;
 #pragma unroll
                for (int dy = 0; dy < D; dy++)
                {
-                  w += bg.b[qy*D + dy + zr]*bx[dy];
+                  const double bx = sBX[(dz*D + dy)*QP + a];
+                  w += Bb[dy]*bx;
                   if (KIND)
                   {
-                     u += bg.b[qy*D + dy + zr]*gx[dy];
-                     v += bg.g[qy*D + dy + zr]*bx[dy];
+                     const double gx = sGX[(dz*D + dy)*QP + a];
+                     u += Bb[dy]*gx;
+                     v += Gb[dy]*bx;
                   }
                }
-               sT[tix(dz, qy, qx)] = w;
-               if (KIND)
+               r1[dz] = u; r2[dz] = v; r3[dz] = w;
+            }
+         }
+
+         // --- z loop in registers: to the quadrature point, D matvec, back to dofs in z
+         // The wave-uniform basis factors are re-read from the kernel-argument segment every
+         // iteration (scalar loads, scalar cache): `zofs` is an opaque 0 that keeps the
+         // compiler from hoisting all 2*Q*D of them out of the batch loop, where they would
+         // not fit the SGPR file and spill to VGPR lanes.
+         asm volatile("s_mov_b32 %0, 0" : "=s"(zofs));
+         double t1[D], t2r[D], t3[D];
+#pragma unroll
+         for (int dz = 0; dz < D; dz++) { t1[dz] = 0.0; t2r[dz] = 0.0; t3[dz] = 0.0; }
+#pragma unroll
+         for (int qz = 0; qz < Q; qz++)
+         {
+            if (PF > 0)
+            {
+               // request the slice PF steps ahead: of this batch, or (ring) of the next one
+               if (qz + PF < Q) { load_slice(bt, qz + PF, O[qz + PF < Q ? qz + PF : 0]); }
+               else if (PERSIST) { load_slice(btn, qz + PF - Q, On[qz + PF >= Q ? qz + PF - Q : 0]); }
+            }
+            if (KIND)
+            {
+               double gX = 0.0, gY = 0.0, gZ = 0.0;
+#pragma unroll
+               for (int dz = 0; dz < D; dz++)
                {
-                  sT[tix(D + dz, qy, qx)] = v;
-                  sT[tix(2*D + dz, qy, qx)] = u;
+                  const double bz = bg.b[qz*D + dz + zofs], gz = bg.g[qz*D + dz + zofs];
+                  gX += bz*r1[dz];
+                  gY += bz*r2[dz];
+                  gZ += gz*r3[dz];
+               }
+               const double O11 = O[qz][0], O12 = O[qz][1], O13 = O[qz][2];
+               const double O22 = O[qz][NC > 3 ? 3 : 0], O23 = O[qz][NC > 4 ? 4 : 0], O33 = O[qz][NC > 5 ? 5 : 0];
+               const double fX = (O11*gX) + (O12*gY) + (O13*gZ);
+               const double fY = (O12*gX) + (O22*gY) + (O23*gZ);
+               const double fZ = (O13*gX) + (O23*gY) + (O33*gZ);
+#pragma unroll
+               for (int dz = 0; dz < D; dz++)
+               {
+                  const double bz = bg.b[qz*D + dz + zofs], gz = bg.g[qz*D + dz + zofs];
+                  t1[dz] += bz*fX;
+                  t2r[dz] += bz*fY;
+                  t3[dz] += gz*fZ;
                }
             }
+            else
+            {
+               double u = 0.0;
+#pragma unroll
+               for (int dz = 0; dz < D; dz++) { u += bg.b[qz*D + dz + zofs]*r3[dz]; }
+               u *= O[qz][0];
+#pragma unroll
+               for (int dz = 0; dz < D; dz++) { t3[dz] += bg.b[qz*D + dz + zofs]*u; }
+            }
+         }
+         // all reads of sBX/sGX done; region A is reused as sT (RB == 2: every thread overwrites
+         // exactly the sR entries it read itself -- no barrier)
+         if (RB != 2) { __syncthreads(); }
+#pragma unroll
+         for (int dz = 0; dz < D; dz++)
+         {
+            sT[tix(dz, b, a)] = t3[dz];
+            if (KIND)
+            {
+               sT[tix(D + dz, b, a)] = t2r[dz];
+               sT[tix(2*D + dz, b, a)] = t1[dz];
+            }
+         }
+         // --- next batch: x values first (needed first; vmcnt retires in order), then pa_data.
+         // The scheduling fence keeps these loads below the z loop: hoisted above it they would
+         // need a second set of 2*NC*Q registers and cost a wave of occupancy.
+         __builtin_amdgcn_sched_barrier(0);
+         if (PERSIST)
+         {
+            load_xv(en);
+            if (PF == 0) { load_O(en, btn); }
          }
          __syncthreads();
-#pragma unroll
-         for (int dz = 0; dz < D; dz++)
+
+         // --- transposed y contraction: thread (qx = a, dy = b); RB: thread t2 = (qx, dz), all dy
+         asm volatile("s_mov_b32 %0, 0" : "=s"(zy));
+         if (RB)
          {
-            r3[dz] = sT[tix(dz, b, a)];
-            r2[dz] = KIND ? sT[tix(D + dz, b, a)] : 0.0;
-            r1[dz] = KIND ? sT[tix(2*D + dz, b, a)] : 0.0;
-         }
-      }
-      else
-      {
-         double Bb[D], Gb[D];
-#pragma unroll
-         for (int dy = 0; dy < D; dy++) { Bb[dy] = sB[b*D + dy + vz]; Gb[dy] = KIND ? sG[b*D + dy + vz] : 0.0; }
-#pragma unroll
-         for (int dz = 0; dz < D; dz++)
-         {
-            double u = 0.0, v = 0.0, w = 0.0;
-#pragma unroll
-            for (int dy = 0; dy < D; dy++)
+            if (t2 < Q*D)
             {
-               const double bx = sBX[(dz*D + dy)*QP + a];
-               w += Bb[dy]*bx;
-               if (KIND)
+               const int qx = t2 % Q, dz = t2 / Q;
+               double v23[D], v1[D];
+#pragma unroll
+               for (int dy = 0; dy < D; dy++) { v23[dy] = 0.0; v1[dy] = 0.0; }
+#pragma unroll
+               for (int qy = 0; qy < Q; qy++)
                {
-                  const double gx = sGX[(dz*D + dy)*QP + a];
-                  u += Bb[dy]*gx;
-                  v += Gb[dy]*bx;
+                  const double T0 = sT[tix(dz, qy, qx)];
+                  const double T1 = KIND ? sT[tix(D + dz, qy, qx)] : 0.0;
+                  const double T2 = KIND ? sT[tix(2*D + dz, qy, qx)] : 0.0;
+#pragma unroll
+                  for (int dy = 0; dy < D; dy++)
+                  {
+                     v23[dy] += bg.b[qy*D + dy + zy]*T0;
+                     if (KIND)
+                     {
+                        v23[dy] += bg.g[qy*D + dy + zy]*T1;
+                        v1[dy] += bg.b[qy*D + dy + zy]*T2;
+                     }
+                  }
                }
-            }
-            r1[dz] = u; r2[dz] = v; r3[dz] = w;
-         }
-      }
-
-      // --- z loop in registers: to the quadrature point, D matvec, back to dofs in z
-      // The wave-uniform basis factors are re-read from the kernel-argument segment every
-      // iteration (scalar loads, scalar cache): `zofs` is an opaque 0 that keeps the
-      // compiler from hoisting all 2*Q*D of them out of the batch loop, where they would
-      // not fit the SGPR file and spill to VGPR lanes.
-      asm volatile("s_mov_b32 %0, 0" : "=s"(zofs));
-      double t1[D], t2r[D], t3[D];
-#pragma unroll
-      for (int dz = 0; dz < D; dz++) { t1[dz] = 0.0; t2r[dz] = 0.0; t3[dz] = 0.0; }
-#pragma unroll
-      for (int qz = 0; qz < Q; qz++)
-      {
-         if (PF > 0)
-         {
-            // request the slice PF steps ahead: of this batch, or (ring) of the next one
-            if (qz + PF < Q) { load_slice(bt, qz + PF, O[qz + PF < Q ? qz + PF : 0]); }
-            else if (PERSIST) { load_slice(btn, qz + PF - Q, On[qz + PF >= Q ? qz + PF - Q : 0]); }
-         }
-         if (KIND)
-         {
-            double gX = 0.0, gY = 0.0, gZ = 0.0;
-#pragma unroll
-            for (int dz = 0; dz < D; dz++)
-            {
-               const double bz = bg.b[qz*D + dz + zofs], gz = bg.g[qz*D + dz + zofs];
-               gX += bz*r1[dz];
-               gY += bz*r2[dz];
-               gZ += gz*r3[dz];
-            }
-            const double O11 = O[qz][0], O12 = O[qz][1], O13 = O[qz][2];
-            const double O22 = O[qz][NC > 3 ? 3 : 0], O23 = O[qz][NC > 4 ? 4 : 0], O33 = O[qz][NC > 5 ? 5 : 0];
-            const double fX = (O11*gX) + (O12*gY) + (O13*gZ);
-            const double fY = (O12*gX) + (O22*gY) + (O23*gZ);
-            const double fZ = (O13*gX) + (O23*gY) + (O33*gZ);
-#pragma unroll
-            for (int dz = 0; dz < D; dz++)
-            {
-               const double bz = bg.b[qz*D + dz + zofs], gz = bg.g[qz*D + dz + zofs];
-               t1[dz] += bz*fX;
-               t2r[dz] += bz*fY;
-               t3[dz] += gz*fZ;
-            }
-         }
-         else
-         {
-            double u = 0.0;
-#pragma unroll
-            for (int dz = 0; dz < D; dz++) { u += bg.b[qz*D + dz + zofs]*r3[dz]; }
-            u *= O[qz][0];
-#pragma unroll
-            for (int dz = 0; dz < D; dz++) { t3[dz] += bg.b[qz*D + dz + zofs]*u; }
-         }
-      }
-      // all reads of sBX/sGX done; region A is reused as sT (RB == 2: every thread overwrites
-      // exactly the sR entries it read itself -- no barrier)
-      if (RB != 2) { __syncthreads(); }
-#pragma unroll
-      for (int dz = 0; dz < D; dz++)
-      {
-         sT[tix(dz, b, a)] = t3[dz];
-         if (KIND)
-         {
-            sT[tix(D + dz, b, a)] = t2r[dz];
-            sT[tix(2*D + dz, b, a)] = t1[dz];
-         }
-      }
-      // --- next batch: x values first (needed first; vmcnt retires in order), then pa_data.
-      // The scheduling fence keeps these loads below the z loop: hoisted above it they would
-      // need a second set of 2*NC*Q registers and cost a wave of occupancy.
-      __builtin_amdgcn_sched_barrier(0);
-      if (PERSIST)
-      {
-         load_xv(en);
-         if (PF == 0) { load_O(en, btn); }
-      }
-      __syncthreads();
-
-      // --- transposed y contraction: thread (qx = a, dy = b); RB: thread t2 = (qx, dz), all dy
-      asm volatile("s_mov_b32 %0, 0" : "=s"(zy));
-      if (RB)
-      {
-         if (t2 < Q*D)
-         {
-            const int qx = t2 % Q, dz = t2 / Q;
-            double v23[D], v1[D];
-#pragma unroll
-            for (int dy = 0; dy < D; dy++) { v23[dy] = 0.0; v1[dy] = 0.0; }
-#pragma unroll
-            for (int qy = 0; qy < Q; qy++)
-            {
-               const double T0 = sT[tix(dz, qy, qx)];
-               const double T1 = KIND ? sT[tix(D + dz, qy, qx)] : 0.0;
-               const double T2 = KIND ? sT[tix(2*D + dz, qy, qx)] : 0.0;
 #pragma unroll
                for (int dy = 0; dy < D; dy++)
                {
-                  v23[dy] += bg.b[qy*D + dy + zy]*T0;
+                  sV[(dz*D + dy)*QP + qx] = v23[dy];
+                  if (KIND) { sV[DDQ + (dz*D + dy)*QP + qx] = v1[dy]; }
+               }
+            }
+         }
+         else if (b < D)
+         {
+            double Bc[Q], Gc[Q];
+#pragma unroll
+            for (int qy = 0; qy < Q; qy++) { Bc[qy] = sB[qy*D + b + vz]; Gc[qy] = KIND ? sG[qy*D + b + vz] : 0.0; }
+#pragma unroll
+            for (int dz = 0; dz < D; dz++)
+            {
+               double v1 = 0.0, v23 = 0.0;
+#pragma unroll
+               for (int qy = 0; qy < Q; qy++)
+               {
+                  v23 += Bc[qy]*sT[tix(dz, qy, a)];
                   if (KIND)
                   {
-                     v23[dy] += bg.g[qy*D + dy + zy]*T1;
-                     v1[dy] += bg.b[qy*D + dy + zy]*T2;
+                     v23 += Gc[qy]*sT[tix(D + dz, qy, a)];
+                     v1 += Bc[qy]*sT[tix(2*D + dz, qy, a)];
+                  }
+               }
+               sV[(dz*D + b)*QP + a] = v23;
+               if (KIND) { sV[DDQ + (dz*D + b)*QP + a] = v1; }
+            }
+         }
+         __syncthreads();
+
+         // --- transposed x contraction and store: thread (dx = a, dy = b); RB: thread t2 = row
+         // (dz,dy), all dx -- D consecutive doubles of yE per thread
+         asm volatile("s_mov_b32 %0, 0" : "=s"(zt));
+         if (RB)
+         {
+            if (t2 < D*D && active)
+            {
+               double V23[Q], V1[Q];
+#pragma unroll
+               for (int qx = 0; qx < Q; qx++) { V23[qx] = sV[t2*QP + qx]; V1[qx] = KIND ? sV[DDQ + t2*QP + qx] : 0.0; }
+               double yv[D];
+#pragma unroll
+               for (int dx = 0; dx < D; dx++)
+               {
+                  double y = 0.0;
+#pragma unroll
+                  for (int qx = 0; qx < Q; qx++)
+                  {
+                     y += bg.b[qx*D + dx + zt]*V23[qx];
+                     if (KIND) { y += bg.g[qx*D + dx + zt]*V1[qx]; }
+                  }
+                  yv[dx] = y;
+               }
+               double *ye = yE + (VEC ? e*va.vd + comp : e)*D3 + t2*D;
+               if (D % 2 == 0)
+               {
+                  double2 *ye2 = reinterpret_cast<double2*>(ye);      // e*D3 + t2*D is even: 16-B aligned
+#pragma unroll
+                  for (int dx = 0; dx < D/2; dx++)
+                  {
+                     double2 o;
+                     if (ACCUM) { o = ye2[dx]; o.x += yv[2*dx]; o.y += yv[2*dx + 1]; }
+                     else { o.x = yv[2*dx]; o.y = yv[2*dx + 1]; }
+                     ye2[dx] = o;
+                  }
+               }
+               else
+               {
+#pragma unroll
+                  for (int dx = 0; dx < D; dx++)
+                  {
+                     if (ACCUM) { ye[dx] += yv[dx]; }
+                     else { ye[dx] = yv[dx]; }
                   }
                }
             }
-#pragma unroll
-            for (int dy = 0; dy < D; dy++)
-            {
-               sV[(dz*D + dy)*QP + qx] = v23[dy];
-               if (KIND) { sV[DDQ + (dz*D + dy)*QP + qx] = v1[dy]; }
-            }
          }
-      }
-      else if (b < D)
-      {
-         double Bc[Q], Gc[Q];
-#pragma unroll
-         for (int qy = 0; qy < Q; qy++) { Bc[qy] = sB[qy*D + b + vz]; Gc[qy] = KIND ? sG[qy*D + b + vz] : 0.0; }
-#pragma unroll
-         for (int dz = 0; dz < D; dz++)
+         else if (a < D && b < D && active)
          {
-            double v1 = 0.0, v23 = 0.0;
+            double Bc[Q], Gc[Q];
 #pragma unroll
-            for (int qy = 0; qy < Q; qy++)
-            {
-               v23 += Bc[qy]*sT[tix(dz, qy, a)];
-               if (KIND)
-               {
-                  v23 += Gc[qy]*sT[tix(D + dz, qy, a)];
-                  v1 += Bc[qy]*sT[tix(2*D + dz, qy, a)];
-               }
-            }
-            sV[(dz*D + b)*QP + a] = v23;
-            if (KIND) { sV[DDQ + (dz*D + b)*QP + a] = v1; }
-         }
-      }
-      __syncthreads();
-
-      // --- transposed x contraction and store: thread (dx = a, dy = b); RB: thread t2 = row
-      // (dz,dy), all dx -- D consecutive doubles of yE per thread
-      asm volatile("s_mov_b32 %0, 0" : "=s"(zt));
-      if (RB)
-      {
-         if (t2 < D*D && active)
-         {
-            double V23[Q], V1[Q];
+            for (int qx = 0; qx < Q; qx++) { Bc[qx] = sB[qx*D + a + vz]; Gc[qx] = KIND ? sG[qx*D + a + vz] : 0.0; }
+            double *ye = yE + (VEC ? e*va.vd + comp : e)*D3 + b*D + a;
 #pragma unroll
-            for (int qx = 0; qx < Q; qx++) { V23[qx] = sV[t2*QP + qx]; V1[qx] = KIND ? sV[DDQ + t2*QP + qx] : 0.0; }
-            double yv[D];
-#pragma unroll
-            for (int dx = 0; dx < D; dx++)
+            for (int dz = 0; dz < D; dz++)
             {
                double y = 0.0;
 #pragma unroll
                for (int qx = 0; qx < Q; qx++)
                {
-                  y += bg.b[qx*D + dx + zt]*V23[qx];
-                  if (KIND) { y += bg.g[qx*D + dx + zt]*V1[qx]; }
+                  y += Bc[qx]*sV[(dz*D + b)*QP + qx];
+                  if (KIND) { y += Gc[qx]*sV[DDQ + (dz*D + b)*QP + qx]; }
                }
-               yv[dx] = y;
-            }
-            double *ye = yE + e*D3 + t2*D;
-            if (D % 2 == 0)
-            {
-               double2 *ye2 = reinterpret_cast<double2*>(ye);      // e*D3 + t2*D is even: 16-B aligned
-#pragma unroll
-               for (int dx = 0; dx < D/2; dx++)
-               {
-                  double2 o;
-                  if (ACCUM) { o = ye2[dx]; o.x += yv[2*dx]; o.y += yv[2*dx + 1]; }
-                  else { o.x = yv[2*dx]; o.y = yv[2*dx + 1]; }
-                  ye2[dx] = o;
-               }
-            }
-            else
-            {
-#pragma unroll
-               for (int dx = 0; dx < D; dx++)
-               {
-                  if (ACCUM) { ye[dx] += yv[dx]; }
-                  else { ye[dx] = yv[dx]; }
-               }
+               if (ACCUM) { ye[dz*D*D] += y; }
+               else { ye[dz*D*D] = y; }
             }
          }
+         // no barrier needed here: the next iteration writes sX (region A), whose last readers
+         // (the transposed y contraction) are behind the barrier above; sV is next written
+         // three barriers from now.
       }
-      else if (a < D && b < D && active)
-      {
-         double Bc[Q], Gc[Q];
-#pragma unroll
-         for (int qx = 0; qx < Q; qx++) { Bc[qx] = sB[qx*D + a + vz]; Gc[qx] = KIND ? sG[qx*D + a + vz] : 0.0; }
-         double *ye = yE + e*D3 + b*D + a;
-#pragma unroll
-         for (int dz = 0; dz < D; dz++)
-         {
-            double y = 0.0;
-#pragma unroll
-            for (int qx = 0; qx < Q; qx++)
-            {
-               y += Bc[qx]*sV[(dz*D + b)*QP + qx];
-               if (KIND) { y += Gc[qx]*sV[DDQ + (dz*D + b)*QP + qx]; }
-            }
-            if (ACCUM) { ye[dz*D*D] += y; }
-            else { ye[dz*D*D] = y; }
-         }
-      }
-      // no barrier needed here: the next iteration writes sX (region A), whose last readers
-      // (the transposed y contraction) are behind the barrier above; sV is next written
-      // three barriers from now.
       if (PF > 0 && PERSIST)
       {
 #pragma unroll
@@ -654,7 +683,7 @@ template <int KIND, bool GATHER, bool ACCUM>
 __global__ void __launch_bounds__(256)
 k_pa_apply_generic(const int D, const int Q, const int64_t ne, const BasisT<MAX_DQ> bg,
                    const double *__restrict__ Dq, const double *__restrict__ x,
-                   const int *__restrict__ gmap, double *__restrict__ yE)
+                   const int *__restrict__ gmap, double *__restrict__ yE, const VecArgs va, const int comp)
 {
    constexpr int NC = KIND ? 6 : 1, NF = KIND ? 3 : 1, NX = KIND ? 2 : 1;
    extern __shared__ __align__(16) double dyn[];
@@ -667,11 +696,24 @@ k_pa_apply_generic(const int D, const int Q, const int64_t ne, const BasisT<MAX_
    const int tid = threadIdx.x, nt = blockDim.x;
    const int64_t e = blockIdx.x;
    for (int i = tid; i < Q*D; i += nt) { sB[i] = bg.b[i]; sG[i] = bg.g[i]; }
+   // va.vd == 0: scalar space; else component `comp` of a vector space (one launch per component)
+   const int64_t eblk = va.vd ? e*va.vd + comp : e;            // E-vector block (D^3,vd,NE)
+   const int64_t dblk = (va.vd && va.d_comp_stride) ? eblk : e;   // pa_data block
    for (int i = tid; i < D3; i += nt)
    {
       double v;
-      if (GATHER) { const int g = gmap[e*D3 + i]; v = (g >= 0) ? x[g] : 0.0; }
-      else { v = x[e*D3 + i]; }
+      if (GATHER)
+      {
+         const int g = gmap[e*D3 + i];
+         if (va.vd)
+         {
+            const int64_t gg = g >= 0 ? g : 0;
+            const int64_t idx = va.byvdim ? gg*va.vd + comp : gg + comp*va.ndofs;
+            v = (g >= 0 && !(va.marker && va.marker[idx])) ? x[idx] : 0.0;
+         }
+         else { v = (g >= 0) ? x[g] : 0.0; }
+      }
+      else { v = x[eblk*D3 + i]; }
       sX[i] = v;
    }
    __syncthreads();
@@ -711,7 +753,7 @@ k_pa_apply_generic(const int D, const int Q, const int64_t ne, const BasisT<MAX_
    for (int i = tid; i < Q3; i += nt)
    {
       const int qq = i % QQ, qz = i/QQ;
-      const double *De = Dq + e*(int64_t)(NC*Q3) + i;
+      const double *De = Dq + dblk*(int64_t)(NC*Q3) + i;
       if (KIND)
       {
          double gX = 0.0, gY = 0.0, gZ = 0.0;
@@ -781,8 +823,8 @@ k_pa_apply_generic(const int D, const int Q, const int64_t ne, const BasisT<MAX_
          y += sB[qx*D + dx]*s1[dyz*Q + qx];
          if (KIND) { y += sG[qx*D + dx]*s1[DDQ + dyz*Q + qx]; }
       }
-      if (ACCUM) { yE[e*D3 + i] += y; }
-      else { yE[e*D3 + i] = y; }
+      if (ACCUM) { yE[eblk*D3 + i] += y; }
+      else { yE[eblk*D3 + i] = y; }
    }
 }
 
@@ -846,7 +888,14 @@ static int apply_pf(int KIND, int D, int Q)
    return 0;
 }
 
-// register-blocked contractions (kernel comment): MFEM_AMD_APPLY_RB=0|1 overrides (tuning aid)
+constexpr int rb_table(int KIND, int D, int Q)
+{
+   if (KIND == 0) { return D >= 4 ? 2 : 1; }
+   if (Q == D) { return (D == 5 || D == 6 || D >= 8) ? 2 : 1; }
+   return D >= 8 ? 2 : (D >= 4 ? 1 : 0);
+}
+
+// register-blocked contractions (kernel comment): MFEM_AMD_APPLY_RB=0|1|2 overrides (tuning aid)
 static int apply_rb(int KIND, int D, int Q)
 {
    static int forced = -2;
@@ -858,9 +907,7 @@ static int apply_rb(int KIND, int D, int Q)
    if (forced >= 0) { return forced; }
    // measured (profiles/r1/sweep_rb_*.txt): level 1 pays from p = 3 on; level 2 adds a little for
    // mass and for the largest elements, where its smaller register footprint matters
-   if (KIND == 0) { return D >= 4 ? 2 : 1; }
-   if (Q == D) { return (D == 5 || D == 6 || D >= 8) ? 2 : 1; }
-   return D >= 8 ? 2 : (D >= 4 ? 1 : 0);
+   return rb_table(KIND, D, Q);
 }
 
 template <int KIND, int D, int Q, bool GATHER, bool ACCUM, bool BLK, int PF = 0, int RB = 0, bool RESOLVED = false>
@@ -905,12 +952,12 @@ static int launch_apply(int64_t ne, const double *B, const double *G, const doub
    if (mode == 0)
    {
       MFA_REQUIRE(nb < (int64_t)2147483647, "pa_apply: too many workgroups (%lld)", (long long)nb);
-      kern1<<<dim3((unsigned)nb), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, 1, bg, Dq, x, gmap, yE);
+      kern1<<<dim3((unsigned)nb), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, 1, bg, Dq, x, gmap, yE, VecArgs{});
    }
    else
    {
       const unsigned grid = (unsigned)(nb < resident[dev] ? nb : resident[dev]);
-      kern<<<dim3(grid), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, mode == 2 ? 1 : 0, bg, Dq, x, gmap, yE);
+      kern<<<dim3(grid), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, mode == 2 ? 1 : 0, bg, Dq, x, gmap, yE, VecArgs{});
    }
    MFA_CHECK_LAUNCH("k_pa_apply");
    return 0;
@@ -953,9 +1000,89 @@ static int run_apply(int D, int Q, int64_t ne, const double *B, const double *G,
       if (int rc = check_hip(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                              "hipFuncSetAttribute")) { return rc; }
    }
-   kern<<<dim3((unsigned)ne), dim3(256), lds, s>>>(D, Q, ne, bg, Dq, x, gmap, yE);
+   kern<<<dim3((unsigned)ne), dim3(256), lds, s>>>(D, Q, ne, bg, Dq, x, gmap, yE, VecArgs{}, 0);
    MFA_CHECK_LAUNCH("k_pa_apply_generic");
    return 0;
+}
+
+
+// ---- vector spaces: one launch, the workgroup loops over the components -------------------
+typedef int (*apply_vec_fn)(int64_t ne, const double *B, const double *G, const double *Dq,
+                            const double *x, const int *gmap, double *yE, VecArgs va, hipStream_t s);
+
+template <int KIND, int D, int Q, bool GATHER, bool ACCUM, bool BLK>
+static int launch_apply_vec(int64_t ne, const double *B, const double *G, const double *Dq,
+                            const double *x, const int *gmap, double *yE, VecArgs va, hipStream_t s)
+{
+   constexpr int NBZ = nbz_for(Q);
+   constexpr int RBV = Q > 3 ? rb_table(KIND, D, Q) : 0;
+   auto kern = k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM, BLK, 0, false, 0, RBV, true>;
+   BasisT<D*Q> bg;
+   fill_basis(bg, D, Q, B, G);
+   const int64_t nb = (ne + NBZ - 1)/NBZ;
+   if (nb == 0) { return 0; }
+   MFA_REQUIRE(nb < (int64_t)2147483647, "pa_apply: too many workgroups (%lld)", (long long)nb);
+   kern<<<dim3((unsigned)nb), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, 1, bg, Dq, x, gmap, yE, va);
+   MFA_CHECK_LAUNCH("k_pa_apply (vector)");
+   return 0;
+}
+
+template <int KIND, bool GATHER, bool ACCUM, bool BLK>
+static apply_vec_fn find_apply_vec(int D, int Q)
+{
+#define MFA_CASE(DD, QQ) \
+   if (D == DD && Q == QQ) { return launch_apply_vec<KIND, DD, QQ, GATHER, ACCUM, BLK>; }
+   MFA_CASE(2, 2) MFA_CASE(2, 3) MFA_CASE(3, 3) MFA_CASE(3, 4) MFA_CASE(4, 4) MFA_CASE(4, 5)
+   MFA_CASE(5, 5) MFA_CASE(5, 6) MFA_CASE(6, 6) MFA_CASE(6, 7) MFA_CASE(7, 7) MFA_CASE(7, 8)
+   MFA_CASE(8, 8) MFA_CASE(8, 9) MFA_CASE(9, 9) MFA_CASE(9, 10)
+#undef MFA_CASE
+   return nullptr;
+}
+
+template <int KIND, bool GATHER, bool ACCUM, bool BLK>
+static int run_apply_vec(int D, int Q, int64_t ne, const double *B, const double *G,
+                         const double *Dq, const double *x, const int *gmap, double *yE,
+                         VecArgs va, hipStream_t s)
+{
+   MFA_REQUIRE(D >= 2 && D <= MAX_D1D && Q >= 1 && Q <= MAX_Q1D && D*Q <= MAX_DQ,
+               "pa_apply: unsupported (D1D,Q1D) = (%d,%d); limits D1D<=%d, Q1D<=%d, D1D*Q1D<=%d",
+               D, Q, MAX_D1D, MAX_Q1D, MAX_DQ);
+   MFA_REQUIRE(B && Dq && x && yE && (KIND == 0 || G) && (!GATHER || gmap), "pa_apply: null pointer argument");
+   MFA_REQUIRE(va.vd >= 1 && va.vd <= 16, "pa_apply: vdim must be in 1..16 (got %d)", va.vd);
+   if (apply_vec_fn f = find_apply_vec<KIND, GATHER, ACCUM, BLK>(D, Q)) { return f(ne, B, G, Dq, x, gmap, yE, va, s); }
+   MFA_REQUIRE(!BLK, "pa_apply: the blocked pa_data layout needs a specialised (D1D,Q1D); (%d,%d) is not registered", D, Q);
+   report_fallback(KIND ? "PAVectorDiffusionApply3D" : "PAVectorMassApply3D", D, Q);
+   if (ne == 0) { return 0; }
+   MFA_REQUIRE(ne < (int64_t)2147483647, "pa_apply: too many elements for the fallback kernel");
+   BasisT<MAX_DQ> bg;
+   fill_basis(bg, D, Q, B, G);
+   constexpr int NF = KIND ? 3 : 1, NX = KIND ? 2 : 1;
+   const size_t lds = sizeof(double)*(size_t)(2*Q*D + D*D*D + NX*D*D*Q + NF*D*Q*Q + NF*Q*Q*Q);
+   MFA_REQUIRE(lds <= 160*1024, "pa_apply: fallback kernel needs %zu B of LDS (> 160 KiB)", lds);
+   auto kern = k_pa_apply_generic<KIND, GATHER, ACCUM>;
+   if (lds > 64*1024)
+   {
+      if (int rc = check_hip(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                             "hipFuncSetAttribute")) { return rc; }
+   }
+   for (int c = 0; c < va.vd; c++)
+   {
+      kern<<<dim3((unsigned)ne), dim3(256), lds, s>>>(D, Q, ne, bg, Dq, x, gmap, yE, va, c);
+      MFA_CHECK_LAUNCH("k_pa_apply_generic (vector)");
+   }
+   return 0;
+}
+
+int pa_apply_L2E_vec(int kind, int layout, int D, int Q, int64_t ne, const double *B, const double *G,
+                     const double *Dq, const int *gmap, const double *x, double *yE, VecArgs va, hipStream_t s)
+{
+   if (layout)
+   {
+      if (kind == 0) { return run_apply_vec<0, true, false, true>(D, Q, ne, B, G, Dq, x, gmap, yE, va, s); }
+      return run_apply_vec<1, true, false, true>(D, Q, ne, B, G, Dq, x, gmap, yE, va, s);
+   }
+   if (kind == 0) { return run_apply_vec<0, true, false, false>(D, Q, ne, B, G, Dq, x, gmap, yE, va, s); }
+   return run_apply_vec<1, true, false, false>(D, Q, ne, B, G, Dq, x, gmap, yE, va, s);
 }
 
 int pa_apply_L2E(int kind, int layout, int D, int Q, int64_t ne, const double *B, const double *G,
@@ -1004,6 +1131,44 @@ extern "C" int mfem_amd_pa_apply_L2E(int kind, int pa_layout, int D1D, int Q1D, 
    MFA_REQUIRE(kind == 0 || kind == 1, "pa_apply_L2E: kind must be 0 (mass) or 1 (diffusion)");
    MFA_REQUIRE(pa_layout == 0 || pa_layout == 1, "pa_apply_L2E: pa_layout must be 0 (MFEM) or 1 (blocked)");
    return pa_apply_L2E(kind, pa_layout, D1D, Q1D, ne, B, G, D, gather_map, x, yE, as_stream(stream));
+}
+
+
+extern "C" int mfem_amd_pa_apply_L2E_vdim(int kind, int pa_layout, int D1D, int Q1D, int64_t ne,
+                                          int vdim, int byvdim, int64_t ndofs,
+                                          const double *B, const double *G, const double *D,
+                                          int64_t d_comp_stride, const int *gather_map,
+                                          const unsigned char *ess_marker, const double *x,
+                                          double *yE, void *stream)
+{
+   MFA_REQUIRE(kind == 0 || kind == 1, "pa_apply_L2E_vdim: kind must be 0 (mass) or 1 (diffusion)");
+   MFA_REQUIRE(pa_layout == 0 || pa_layout == 1, "pa_apply_L2E_vdim: pa_layout must be 0 (MFEM) or 1 (blocked)");
+   MFA_REQUIRE(ndofs >= 0 && d_comp_stride >= 0, "pa_apply_L2E_vdim: bad sizes");
+   VecArgs va = {vdim, byvdim ? 1 : 0, ndofs, ess_marker, d_comp_stride};
+   return pa_apply_L2E_vec(kind, pa_layout, D1D, Q1D, ne, B, G, D, gather_map, x, yE, va, as_stream(stream));
+}
+
+extern "C" int mfem_amd_pa_vector_diffusion_apply_3d(int D1D, int Q1D, int64_t ne, int vdim, int coeff_vdim,
+                                                     const double *B, const double *G, const double *D,
+                                                     const double *xE, double *yE, void *stream)
+{
+   MFA_REQUIRE(coeff_vdim == 1 || coeff_vdim == vdim,
+               "pa_vector_diffusion_apply_3d: scalar and vector coefficients only (coeff_vdim = %d, vdim = %d); "
+               "matrix coefficients are not built", coeff_vdim, vdim);
+   // the reference stores one (Q^3,6) block per component for scalar and vector coefficients alike
+   VecArgs va = {vdim, 0, 0, nullptr, 1};
+   return run_apply_vec<1, false, true, false>(D1D, Q1D, ne, B, G, D, xE, nullptr, yE, va, as_stream(stream));
+}
+
+extern "C" int mfem_amd_pa_vector_mass_apply_3d(int D1D, int Q1D, int64_t ne, int vdim, int coeff_vdim,
+                                                const double *B, const double *D, const double *xE,
+                                                double *yE, void *stream)
+{
+   MFA_REQUIRE(coeff_vdim == 1 || coeff_vdim == vdim,
+               "pa_vector_mass_apply_3d: scalar and vector coefficients only (coeff_vdim = %d, vdim = %d); "
+               "matrix coefficients are not built", coeff_vdim, vdim);
+   VecArgs va = {vdim, 0, 0, nullptr, coeff_vdim == 1 ? 0 : 1};   // (Q^3,coeff_vdim,NE)
+   return run_apply_vec<0, false, true, false>(D1D, Q1D, ne, B, nullptr, D, xE, nullptr, yE, va, as_stream(stream));
 }
 
 extern "C" int64_t mfem_amd_pa_data_size(int kind, int pa_layout, int Q1D, int64_t ne)

@@ -160,6 +160,64 @@ k_scatter(const int64_t ndofs, const int *__restrict__ offsets,
    }
 }
 
+// Vector spaces (ElementRestriction with vdim > 1, fem/restriction.cpp:152-180): row i is a
+// vdof -- byNODES i = c*ndofs + dof, byVDIM i = dof*vd + c -- and sums the entries
+// xE[(idx % nd) + nd*(c + vd*(idx / nd))] of its scalar dof's CSR row, in the same order.
+struct ScatVec { int vd, byvdim, nd; int64_t ndofs; };
+
+template <int MODE, bool DOT>
+__global__ void __launch_bounds__(256)
+k_scatter_vec(const ScatVec sv, const int *__restrict__ offsets,
+              const int *__restrict__ indices, const double *__restrict__ xE,
+              double *__restrict__ y, const unsigned char *__restrict__ marker,
+              const double *__restrict__ xin, const double *__restrict__ w,
+              double *__restrict__ partials, const int *__restrict__ skip)
+{
+   __shared__ double s4[4];
+   if (skip && *skip) { return; }
+   const int64_t n = sv.ndofs*sv.vd;
+   double prod = 0.0;
+   for (int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x; i < n; i += (int64_t)gridDim.x*256)
+   {
+      const int64_t dof = sv.byvdim ? i/sv.vd : i % sv.ndofs;
+      const int c = (int)(sv.byvdim ? i % sv.vd : i/sv.ndofs);
+      const int o0 = offsets[dof], o1 = offsets[dof + 1];
+      double v = 0.0;
+      for (int j0 = o0; j0 < o1; j0 += 8)
+      {
+         const int m = o1 - j0 < 8 ? o1 - j0 : 8;
+         int id[8];
+         double t[8];
+#pragma unroll
+         for (int k = 0; k < 8; k++) { id[k] = indices[j0 + (k < m ? k : m - 1)]; }
+#pragma unroll
+         for (int k = 0; k < 8; k++)
+         {
+            const int64_t a = id[k] >= 0 ? id[k] : -1 - id[k];
+            t[k] = xE[(a % sv.nd) + (int64_t)sv.nd*(c + sv.vd*(a/sv.nd))];
+         }
+#pragma unroll
+         for (int k = 0; k < 8; k++)
+         {
+            if (k < m) { v += (id[k] >= 0 || MODE == 2) ? t[k] : -t[k]; }
+         }
+      }
+      if (marker)
+      {
+         const unsigned char mk = marker[i];
+         if (mk) { v = (mk == 1) ? xin[i] : 0.0; }
+      }
+      if (MODE == 1) { v += y[i]; }
+      y[i] = v;
+      if (DOT) { prod += w[i]*v; }
+   }
+   if (DOT)
+   {
+      const double r = block_sum_256(prod, s4);
+      if (threadIdx.x == 0) { partials[blockIdx.x] = r; }
+   }
+}
+
 __global__ void __launch_bounds__(256)
 k_set_marker(const int64_t n, const int *__restrict__ list, unsigned char *__restrict__ marker)
 {
@@ -236,9 +294,46 @@ int scatter_dot(int64_t ndofs, const int *offsets, const int *indices, const dou
    return 0;
 }
 
+// vector-space variant of scatter_dot (rows = vdofs)
+int scatter_dot_vec(int64_t ndofs, int nd, int vd, int byvdim, const int *offsets, const int *indices,
+                    const double *xE, double *y, const unsigned char *marker, const double *xin,
+                    const double *w, double *partials, int nblocks, const int *skip, hipStream_t s)
+{
+   const ScatVec sv = {vd, byvdim, nd, ndofs};
+   if (w)
+   {
+      k_scatter_vec<0, true><<<dim3(nblocks), dim3(256), 0, s>>>(sv, offsets, indices, xE, y, marker, xin, w, partials, skip);
+   }
+   else
+   {
+      k_scatter_vec<0, false><<<dim3(nblocks), dim3(256), 0, s>>>(sv, offsets, indices, xE, y, marker, xin, nullptr, nullptr, skip);
+   }
+   MFA_CHECK_LAUNCH("k_scatter_vec");
+   return 0;
+}
+
 } // namespace mfa
 
 using namespace mfa;
+
+extern "C" int mfem_amd_restrict_scatter_vdim(int64_t ndofs, int nd, int vdim, int byvdim,
+                                              const int *offsets, const int *indices,
+                                              const double *xE, double *y, int add, int absv,
+                                              void *stream)
+{
+   if (ndofs == 0) { return 0; }
+   MFA_REQUIRE(ndofs > 0 && nd > 0 && vdim >= 1 && offsets && indices && xE && y, "restrict_scatter_vdim: bad arguments");
+   MFA_REQUIRE(!(add && absv), "restrict_scatter_vdim: add and abs cannot be combined");
+   MFA_REQUIRE(ndofs*vdim < ((int64_t)1 << 39), "restrict_scatter_vdim: too many vdofs");
+   const ScatVec sv = {vdim, byvdim ? 1 : 0, nd, ndofs};
+   const unsigned nb = grid_for(ndofs*vdim);
+   hipStream_t s = as_stream(stream);
+   if (absv) { k_scatter_vec<2, false><<<dim3(nb), dim3(256), 0, s>>>(sv, offsets, indices, xE, y, nullptr, nullptr, nullptr, nullptr, nullptr); }
+   else if (add) { k_scatter_vec<1, false><<<dim3(nb), dim3(256), 0, s>>>(sv, offsets, indices, xE, y, nullptr, nullptr, nullptr, nullptr, nullptr); }
+   else { k_scatter_vec<0, false><<<dim3(nb), dim3(256), 0, s>>>(sv, offsets, indices, xE, y, nullptr, nullptr, nullptr, nullptr, nullptr); }
+   MFA_CHECK_LAUNCH("k_scatter_vec");
+   return 0;
+}
 
 extern "C" int mfem_amd_restrict_gather(int64_t nedofs, const int *gather_map,
                                         const double *x, double *yE, void *stream)

@@ -21,6 +21,11 @@ namespace mfa
 
 constexpr int RED_BLOCKS_MAX = 8192;       // partials per reduction
 
+int pa_apply_L2E_vec(int kind, int layout, int D, int Q, int64_t ne, const double *B, const double *G,
+                     const double *Dq, const int *gmap, const double *x, double *yE, VecArgs va, hipStream_t s);
+int scatter_dot_vec(int64_t ndofs, int nd, int vd, int byvdim, const int *offsets, const int *indices,
+                    const double *xE, double *y, const unsigned char *marker, const double *xin,
+                    const double *w, double *partials, int nblocks, const int *skip, hipStream_t s);
 int pa_apply_L2E(int kind, int layout, int D, int Q, int64_t ne, const double *B, const double *G,
                  const double *Dq, const int *gmap, const double *x, double *yE, hipStream_t s);
 int scatter_dot(int64_t ndofs, const int *offsets, const int *indices, const double *xE,
@@ -320,10 +325,21 @@ static int constrained_mult(const mfem_amd_pa_operator *op, const mfem_amd_comm 
                             const int *skip, hipStream_t s)
 {
    const bool ess = op->ness > 0;
-   const int *gm = ess ? op->masked_gather_map : op->gather_map;
-   MFA_REQUIRE(gm, "pa operator: %s is NULL", ess ? "masked_gather_map" : "gather_map");
    MFA_REQUIRE(!ess || op->ess_marker, "pa operator: ess_marker is NULL");
    MFA_REQUIRE(op->yE && op->offsets && op->indices && op->pa_data, "pa operator: null array");
+   if (op->vdim > 0)
+   {
+      // vector space: the essential marker is applied in the gather, rows are vdofs
+      MFA_REQUIRE(!comm, "pa operator: the partitioned path is built for scalar spaces only");
+      MFA_REQUIRE(op->gather_map, "pa operator: gather_map is NULL");
+      const VecArgs va = {op->vdim, op->byvdim ? 1 : 0, op->ndofs, ess ? op->ess_marker : nullptr, op->pa_comp_stride};
+      if (int rc = pa_apply_L2E_vec(op->kind, op->pa_layout, op->D1D, op->Q1D, op->ne, op->B, op->G, op->pa_data,
+                                    op->gather_map, x, op->yE, va, s)) { return rc; }
+      return scatter_dot_vec(op->ndofs, op->D1D*op->D1D*op->D1D, op->vdim, op->byvdim ? 1 : 0, op->offsets, op->indices,
+                             op->yE, y, ess ? op->ess_marker : nullptr, x, w, partials, nb, skip, s);
+   }
+   const int *gm = ess ? op->masked_gather_map : op->gather_map;
+   MFA_REQUIRE(gm, "pa operator: %s is NULL", ess ? "masked_gather_map" : "gather_map");
    if (comm)
    {
       if (int rc = comm->forward(comm->ctx, x, (void*)s)) { set_error("comm forward exchange failed (%d)", rc); return rc; }
@@ -345,8 +361,9 @@ extern "C" int mfem_amd_pa_constrained_mult(const mfem_amd_pa_operator *op, cons
 {
    MFA_REQUIRE(op && x && y, "pa_constrained_mult: bad arguments");
    MFA_REQUIRE(x != y, "pa_constrained_mult: x and y must not alias");
-   const unsigned nb = (unsigned)((op->ndofs + 255)/256);
-   if (op->ndofs == 0) { return 0; }
+   const int64_t n = op->ndofs*(op->vdim > 0 ? op->vdim : 1);
+   const unsigned nb = (unsigned)((n + 255)/256);
+   if (n == 0) { return 0; }
    return constrained_mult(op, nullptr, const_cast<double*>(x), y, nullptr, nullptr, (int)nb, nullptr, as_stream(stream));
 }
 
@@ -376,7 +393,7 @@ static int pcg_impl(const mfem_amd_pa_operator *op, const mfem_amd_comm *comm, c
    MFA_REQUIRE(max_iter >= 0, "pcg_pa: max_iter < 0");
    MFA_REQUIRE(!comm || (comm->allreduce_sum && comm->forward && comm->reverse), "pcg_pa_par: incomplete communicator");
    if (check_every < 1) { check_every = 1; }
-   const int64_t n = op->ndofs;
+   const int64_t n = op->ndofs*(op->vdim > 0 ? op->vdim : 1);   // unknowns (vdofs of a vector space)
    char *ws = (char*)workspace;
    double *r = (double*)ws; ws += align_up(n*8, 256);
    double *d = (double*)ws; ws += align_up(n*8, 256);

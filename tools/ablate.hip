@@ -12,7 +12,7 @@ static int run(int64_t ne, const double *B, const double *G, const double *Dq, c
    const int64_t nb = (ne + NBZ - 1)/NBZ;
    int64_t grid = 256*(int64_t)grid_per_cu;
    if (grid > nb) { grid = nb; }
-   k_pa_apply<1, D, Q, NBZ, true, false, BLK, ABL><<<dim3((unsigned)grid), dim3(Q, Q, NBZ), 0, 0>>>(ne, nb, (ABL & 256) ? 0 : 1, bg, Dq, x, gmap, yE);
+   k_pa_apply<1, D, Q, NBZ, true, false, BLK, ABL><<<dim3((unsigned)grid), dim3(Q, Q, NBZ), 0, 0>>>(ne, nb, (ABL & 256) ? 0 : 1, bg, Dq, x, gmap, yE, mfa::VecArgs{});
    return (int)hipGetLastError();
 }
 
