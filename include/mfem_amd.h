@@ -220,7 +220,8 @@ int mfem_amd_pa_apply_L2E_vdim(int kind, int pa_layout, int D1D, int Q1D, int64_
 /* VectorDiffusionIntegrator::AddMultPA at the dispatch-table seam
  * (ApplyKernelType, fem/bilininteg.hpp; SmemPAVectorDiffusionApply3D,
  * fem/integ/bilininteg_vecdiffusion_pa.hpp:108-170): yE += A xE on (D,D,D,vdim,NE) E-vectors;
- * D is the reference's pa_data (Q,Q,Q,6,vdim,NE) (bilininteg_vecdiffusion_pa.cpp:228-290).
+ * D is the reference's pa_data (Q,Q,Q,9,vdim,NE): dim*dim planes allocated per component, the
+ * symmetric six filled and read (bilininteg_vecdiffusion_pa.cpp:133-134,228-290).
  * coeff_vdim 1 or vdim; matrix coefficients (vdim^2) are rejected. */
 int mfem_amd_pa_vector_diffusion_apply_3d(int D1D, int Q1D, int64_t ne, int vdim, int coeff_vdim,
                                           const double *B, const double *G, const double *D,

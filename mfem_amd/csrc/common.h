@@ -98,6 +98,8 @@ struct VecArgs
    const unsigned char *marker;   // optional, vd*ndofs bytes indexed like x: nonzero reads as 0.0 (essential dofs)
    int64_t d_comp_stride;         // 0: every component uses the same pa_data; else blocked layout: doubles between
                                   // the components' arrays; MFEM layout: nonzero = (Q^3,NC,vd,NE) as the reference
+   int64_t d_block;               // MFEM layout: doubles per (element, component) block; 0 = NC*Q^3.  The reference's
+                                  // vector diffusion allocates dim*dim = 9 planes per block and fills 6
 };
 
 // Workgroup sum for blockDim.x == 256 (4 waves); result valid in thread 0.

@@ -234,7 +234,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
       }
       const int64_t ec = e < elast ? e : elast;
       const int64_t blk = (VEC && va.d_comp_stride) ? ec*va.vd + comp : ec;   // (Q^3,NC,vd,NE) or (Q^3,NC,NE)
-      const double *De = Dq + blk*(int64_t)(NC*Q3) + b*Q + a;
+      const double *De = Dq + blk*((VEC && va.d_block) ? va.d_block : (int64_t)(NC*Q3)) + b*Q + a;
 #pragma unroll
       for (int qz = 0; qz < Q; qz++)
       {
@@ -753,7 +753,7 @@ k_pa_apply_generic(const int D, const int Q, const int64_t ne, const BasisT<MAX_
    for (int i = tid; i < Q3; i += nt)
    {
       const int qq = i % QQ, qz = i/QQ;
-      const double *De = Dq + dblk*(int64_t)(NC*Q3) + i;
+      const double *De = Dq + dblk*((va.vd && va.d_block) ? va.d_block : (int64_t)(NC*Q3)) + i;
       if (KIND)
       {
          double gX = 0.0, gY = 0.0, gZ = 0.0;
@@ -1144,7 +1144,7 @@ extern "C" int mfem_amd_pa_apply_L2E_vdim(int kind, int pa_layout, int D1D, int 
    MFA_REQUIRE(kind == 0 || kind == 1, "pa_apply_L2E_vdim: kind must be 0 (mass) or 1 (diffusion)");
    MFA_REQUIRE(pa_layout == 0 || pa_layout == 1, "pa_apply_L2E_vdim: pa_layout must be 0 (MFEM) or 1 (blocked)");
    MFA_REQUIRE(ndofs >= 0 && d_comp_stride >= 0, "pa_apply_L2E_vdim: bad sizes");
-   VecArgs va = {vdim, byvdim ? 1 : 0, ndofs, ess_marker, d_comp_stride};
+   VecArgs va = {vdim, byvdim ? 1 : 0, ndofs, ess_marker, d_comp_stride, 0};
    return pa_apply_L2E_vec(kind, pa_layout, D1D, Q1D, ne, B, G, D, gather_map, x, yE, va, as_stream(stream));
 }
 
@@ -1155,8 +1155,10 @@ extern "C" int mfem_amd_pa_vector_diffusion_apply_3d(int D1D, int Q1D, int64_t n
    MFA_REQUIRE(coeff_vdim == 1 || coeff_vdim == vdim,
                "pa_vector_diffusion_apply_3d: scalar and vector coefficients only (coeff_vdim = %d, vdim = %d); "
                "matrix coefficients are not built", coeff_vdim, vdim);
-   // the reference stores one (Q^3,6) block per component for scalar and vector coefficients alike
-   VecArgs va = {vdim, 0, 0, nullptr, 1};
+   // the reference stores one block per component for scalar and vector coefficients alike, and
+   // allocates dim*dim = 9 planes per block of which the symmetric 6 are filled and read
+   // (bilininteg_vecdiffusion_pa.cpp:133-134, 228-290)
+   VecArgs va = {vdim, 0, 0, nullptr, 1, 9*(int64_t)Q1D*Q1D*Q1D};
    return run_apply_vec<1, false, true, false>(D1D, Q1D, ne, B, G, D, xE, nullptr, yE, va, as_stream(stream));
 }
 
@@ -1167,7 +1169,7 @@ extern "C" int mfem_amd_pa_vector_mass_apply_3d(int D1D, int Q1D, int64_t ne, in
    MFA_REQUIRE(coeff_vdim == 1 || coeff_vdim == vdim,
                "pa_vector_mass_apply_3d: scalar and vector coefficients only (coeff_vdim = %d, vdim = %d); "
                "matrix coefficients are not built", coeff_vdim, vdim);
-   VecArgs va = {vdim, 0, 0, nullptr, coeff_vdim == 1 ? 0 : 1};   // (Q^3,coeff_vdim,NE)
+   VecArgs va = {vdim, 0, 0, nullptr, coeff_vdim == 1 ? 0 : 1, 0};   // (Q^3,coeff_vdim,NE)
    return run_apply_vec<0, false, true, false>(D1D, Q1D, ne, B, nullptr, D, xE, nullptr, yE, va, as_stream(stream));
 }
 

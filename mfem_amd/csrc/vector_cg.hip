@@ -332,7 +332,7 @@ static int constrained_mult(const mfem_amd_pa_operator *op, const mfem_amd_comm 
       // vector space: the essential marker is applied in the gather, rows are vdofs
       MFA_REQUIRE(!comm, "pa operator: the partitioned path is built for scalar spaces only");
       MFA_REQUIRE(op->gather_map, "pa operator: gather_map is NULL");
-      const VecArgs va = {op->vdim, op->byvdim ? 1 : 0, op->ndofs, ess ? op->ess_marker : nullptr, op->pa_comp_stride};
+      const VecArgs va = {op->vdim, op->byvdim ? 1 : 0, op->ndofs, ess ? op->ess_marker : nullptr, op->pa_comp_stride, 0};
       if (int rc = pa_apply_L2E_vec(op->kind, op->pa_layout, op->D1D, op->Q1D, op->ne, op->B, op->G, op->pa_data,
                                     op->gather_map, x, op->yE, va, s)) { return rc; }
       return scatter_dot_vec(op->ndofs, op->D1D*op->D1D*op->D1D, op->vdim, op->byvdim ? 1 : 0, op->offsets, op->indices,

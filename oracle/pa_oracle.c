@@ -756,6 +756,69 @@ void orc_domain_lf_3d(int D1D, int Q1D, int64_t ne, const double *B, const doubl
 }
 
 /* ---------------------------------------------------------------------------------
+ * Vector H1 spaces (vdim components of one scalar space; CEED BP2/BP4/BP6).
+ * ------------------------------------------------------------------------------ */
+/* ElementRestriction::TAddMultTranspose<ADD> / AbsMultTranspose for vdim > 1
+ * (fem/restriction.cpp:152-180, 196-221): the scalar rows, per component, reading
+ * xE(idx % nd, c, idx / nd). */
+void orc_restriction_mult_transpose_vdim(int64_t ndofs, int nd, int vd, int byvdim,
+                                         const int *offsets, const int *indices,
+                                         const double *xE, double *y, int add, int absv)
+{
+   #pragma omp parallel for schedule(static)
+   for (int64_t i = 0; i < ndofs; i++)
+   {
+      const int offset = offsets[i], next_offset = offsets[i + 1];
+      for (int c = 0; c < vd; ++c)
+      {
+         double dof_value = 0;
+         for (int j = offset; j < next_offset; ++j)
+         {
+            const int64_t idx_j = (indices[j] >= 0) ? indices[j] : -1 - indices[j];
+            const double v = xE[(idx_j % nd) + nd*(c + (int64_t)vd*(idx_j/nd))];
+            dof_value += (indices[j] >= 0 || absv) ? v : -v;
+         }
+         const int64_t k = byvdim ? c + (int64_t)vd*i : i + c*ndofs;
+         if (add) { y[k] += dof_value; }
+         else { y[k] = dof_value; }
+      }
+   }
+}
+
+/* VectorDiffusionIntegrator::AddMultPA, 3D, scalar or vector coefficient
+ * (fem/integ/bilininteg_vecdiffusion_pa.hpp:108-170: for every component i the scalar
+ * diffusion kernel body with block k = i of pa_data (Q,Q,Q,9,vdim,NE) -- dim*dim planes
+ * allocated, the symmetric six filled, bilininteg_vecdiffusion_pa.cpp:133-134,228-290);
+ * E-vectors (D,D,D,vdim,NE). */
+void orc_vector_diffusion_apply_3d(int D1D, int Q1D, int64_t ne, int vdim, const double *B,
+                                   const double *G, const double *Dd, const double *xE, double *yE)
+{
+   const int64_t nd = (int64_t)D1D*D1D*D1D, nq6 = 9*(int64_t)Q1D*Q1D*Q1D;
+   for (int64_t e = 0; e < ne; e++)
+      for (int c = 0; c < vdim; c++)
+      {
+         const int64_t blk = e*vdim + c;
+         orc_diffusion_apply_3d(D1D, Q1D, 1, B, G, Dd + blk*nq6, xE + blk*nd, yE + blk*nd);
+      }
+}
+
+/* VectorMassIntegrator::AddMultPA, 3D (fem/integ/bilininteg_vecmass_pa.hpp; pa_data
+ * (Q,Q,Q,coeff_vdim,NE), bilininteg_vecmass_pa.cpp:118-160): coeff_vdim = 1 (one scalar
+ * field for all components) or vdim. */
+void orc_vector_mass_apply_3d(int D1D, int Q1D, int64_t ne, int vdim, int coeff_vdim,
+                              const double *B, const double *Dd, const double *xE, double *yE)
+{
+   const int64_t nd = (int64_t)D1D*D1D*D1D, nq = (int64_t)Q1D*Q1D*Q1D;
+   for (int64_t e = 0; e < ne; e++)
+      for (int c = 0; c < vdim; c++)
+      {
+         const int64_t blk = e*vdim + c;
+         const double *De = Dd + (coeff_vdim == 1 ? e : blk)*nq;
+         orc_mass_apply_3d(D1D, Q1D, 1, B, De, xE + blk*nd, yE + blk*nd);
+      }
+}
+
+/* ---------------------------------------------------------------------------------
  * The L->L operator and the Krylov path.
  * ------------------------------------------------------------------------------ */
 typedef struct
@@ -767,13 +830,28 @@ typedef struct
    const int *gather_map, *offsets, *indices;
    int ness; const int *ess;      /* essential true dofs (constraint_list) */
    double *xE, *yE, *w, *z;       /* work */
+   /* vector spaces: vdim = 0 scalar; else vdim components, ordering byNODES (0) / byVDIM (1),
+    * pa_data as the reference's vector integrators store it, coeff_vdim = 1 or vdim */
+   int vdim, byvdim, coeff_vdim;
 } orc_op;
+
+static int64_t orc_size(const orc_op *op) { return op->ndofs*(op->vdim > 0 ? op->vdim : 1); }
 
 /* PABilinearFormExtension::MultInternal, H1 branch (fem/bilinearform_ext.cpp:530-559). */
 void orc_pa_mult(const orc_op *op, const double *x, double *y)
 {
    const int nd = op->D1D*op->D1D*op->D1D;
    const int64_t nE = op->ne*nd;
+   if (op->vdim > 0)
+   {
+      const int vd = op->vdim;
+      orc_restriction_mult(nE, nd, vd, op->byvdim, op->ndofs, op->gather_map, x, op->xE);
+      memset(op->yE, 0, sizeof(double)*nE*vd);
+      if (op->kind == 0) { orc_vector_mass_apply_3d(op->D1D, op->Q1D, op->ne, vd, op->coeff_vdim, op->B, op->pa_data, op->xE, op->yE); }
+      else { orc_vector_diffusion_apply_3d(op->D1D, op->Q1D, op->ne, vd, op->B, op->G, op->pa_data, op->xE, op->yE); }
+      orc_restriction_mult_transpose_vdim(op->ndofs, nd, vd, op->byvdim, op->offsets, op->indices, op->yE, y, 0, 0);
+      return;
+   }
    orc_restriction_mult(nE, nd, 1, 0, op->ndofs, op->gather_map, x, op->xE);
    memset(op->yE, 0, sizeof(double)*nE);
    if (op->kind == 0) { orc_mass_apply_3d(op->D1D, op->Q1D, op->ne, op->B, op->pa_data, op->xE, op->yE); }
@@ -795,7 +873,7 @@ void orc_pa_diag(const orc_op *op, double *diag)
 /* ConstrainedOperator::ConstrainedMult, DIAG_ONE (linalg/operator.cpp:586-646). */
 void orc_constrained_mult(const orc_op *op, const double *x, double *y)
 {
-   const int64_t n = op->ndofs;
+   const int64_t n = orc_size(op);
    if (op->ness == 0) { orc_pa_mult(op, x, y); return; }
    memcpy(op->z, x, sizeof(double)*n);
    for (int i = 0; i < op->ness; i++) { op->z[op->ess[i]] = 0.0; }
@@ -807,7 +885,7 @@ void orc_constrained_mult(const orc_op *op, const double *x, double *y)
  * w = 0; w[ess] = x[ess]; b -= A w; b[ess] = x[ess]. */
 void orc_eliminate_rhs(const orc_op *op, const double *x, double *b)
 {
-   const int64_t n = op->ndofs;
+   const int64_t n = orc_size(op);
    memset(op->w, 0, sizeof(double)*n);
    for (int i = 0; i < op->ness; i++) { op->w[op->ess[i]] = x[op->ess[i]]; }
    orc_pa_mult(op, op->w, op->z);
@@ -837,7 +915,7 @@ static double orc_dot(int64_t n, const double *a, const double *b)
 int orc_pcg(const orc_op *op, const double *dinv, const double *b, double *x,
             double rel_tol, double abs_tol, int max_iter, double *hist, int *converged)
 {
-   const int64_t n = op->ndofs;
+   const int64_t n = orc_size(op);
    double *r = (double*)malloc(sizeof(double)*n), *d = (double*)malloc(sizeof(double)*n),
           *z = (double*)malloc(sizeof(double)*n);
    double r0, den, nom, betanom = 0, alpha, beta;

@@ -29,7 +29,8 @@ class OrcOp(C.Structure):
                 ("B", C.c_void_p), ("G", C.c_void_p), ("pa_data", C.c_void_p),
                 ("gather_map", C.c_void_p), ("offsets", C.c_void_p), ("indices", C.c_void_p),
                 ("ness", C.c_int), ("ess", C.c_void_p),
-                ("xE", C.c_void_p), ("yE", C.c_void_p), ("w", C.c_void_p), ("z", C.c_void_p)]
+                ("xE", C.c_void_p), ("yE", C.c_void_p), ("w", C.c_void_p), ("z", C.c_void_p),
+                ("vdim", C.c_int), ("byvdim", C.c_int), ("coeff_vdim", C.c_int)]
 
 
 def _sig(name, res, *args):
@@ -55,6 +56,9 @@ _sig("orc_mass_apply_3d", None, C.c_int, C.c_int, i64, _d, _d, _d, _d)
 _sig("orc_diffusion_diag_3d", None, C.c_int, C.c_int, i64, _d, _d, _d, _d)
 _sig("orc_mass_diag_3d", None, C.c_int, C.c_int, i64, _d, _d, _d)
 _sig("orc_domain_lf_3d", None, C.c_int, C.c_int, i64, _d, _d, _d, C.c_double, _d)
+_sig("orc_restriction_mult_transpose_vdim", None, i64, C.c_int, C.c_int, C.c_int, _i, _i, _d, _d, C.c_int, C.c_int)
+_sig("orc_vector_diffusion_apply_3d", None, C.c_int, C.c_int, i64, C.c_int, _d, _d, _d, _d, _d)
+_sig("orc_vector_mass_apply_3d", None, C.c_int, C.c_int, i64, C.c_int, C.c_int, _d, _d, _d, _d)
 _sig("orc_pa_mult", None, C.POINTER(OrcOp), _d, _d)
 _sig("orc_pa_diag", None, C.POINTER(OrcOp), _d)
 _sig("orc_constrained_mult", None, C.POINTER(OrcOp), _d, _d)
@@ -104,19 +108,22 @@ def restriction_build(ne, dof, ndofs, elem2dof, dof_map):
 class Operator:
     """L->L PA operator on the oracle (keeps numpy arrays alive)."""
 
-    def __init__(self, kind, D1D, Q1D, ne, ndofs, B, G, pa_data, gather_map, offsets, indices, ess=None):
+    def __init__(self, kind, D1D, Q1D, ne, ndofs, B, G, pa_data, gather_map, offsets, indices, ess=None,
+                 vdim=0, byvdim=0, coeff_vdim=1):
+        vd = max(1, vdim)
         self.keep = dict(B=np.ascontiguousarray(B, np.float64), G=np.ascontiguousarray(G, np.float64),
                          pa=np.ascontiguousarray(pa_data, np.float64),
                          g=np.ascontiguousarray(gather_map, np.int32),
                          o=np.ascontiguousarray(offsets, np.int32),
                          i=np.ascontiguousarray(indices, np.int32),
                          ess=np.ascontiguousarray(ess if ess is not None else [], np.int32),
-                         xE=np.zeros(ne*D1D**3), yE=np.zeros(ne*D1D**3), w=np.zeros(ndofs), z=np.zeros(ndofs))
+                         xE=np.zeros(ne*D1D**3*vd), yE=np.zeros(ne*D1D**3*vd), w=np.zeros(ndofs*vd), z=np.zeros(ndofs*vd))
         k = self.keep
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         self.op = OrcOp(kind, D1D, Q1D, ne, ndofs, p(k["B"]), p(k["G"]), p(k["pa"]), p(k["g"]), p(k["o"]),
-                        p(k["i"]), len(k["ess"]), p(k["ess"]), p(k["xE"]), p(k["yE"]), p(k["w"]), p(k["z"]))
-        self.n = ndofs
+                        p(k["i"]), len(k["ess"]), p(k["ess"]), p(k["xE"]), p(k["yE"]), p(k["w"]), p(k["z"]),
+                        vdim, byvdim, coeff_vdim)
+        self.n = ndofs*vd
 
     def mult(self, x):
         y = np.zeros(self.n); lib.orc_pa_mult(C.byref(self.op), np.ascontiguousarray(x), y); return y

@@ -79,7 +79,7 @@ def test_vector_apply_is_the_scalar_apply_per_component(name, byvdim, layout):
 @pytest.mark.parametrize("name", ["cart2_bp3_p3", "cart2_bp1_p4", "toroid-hex_diff_p3", "fichera-q3_massvar_p2"])
 def test_vector_integrator_seam_with_per_component_data(name):
     """VectorDiffusion/VectorMassIntegrator::AddMultPA on E-vectors with the reference's pa_data layout
-    ((Q^3,6,vdim,NE) / (Q^3,coeff_vdim,NE)) and a different coefficient per component: every component
+    ((Q^3,9,vdim,NE), six planes used / (Q^3,coeff_vdim,NE)) and a different coefficient per component: every component
     equals the scalar integrator applied with that component's data, and yE is ADDED to."""
     from gpu_helpers import dev, hB, host, ptr, zeros
     from mfem_amd import capi
@@ -91,6 +91,9 @@ def test_vector_integrator_seam_with_per_component_data(name):
     pa = np.asarray(c["pa_data"]).reshape(NE, nc, Q3)
     scale = [1.0, 0.5, 2.0]                                   # exact in binary: comp k = scale[k] * scalar operator
     pav = np.stack([pa*s for s in scale], axis=1)            # (NE, vd, nc, Q3) = (Q^3,nc,vd,NE) column-major
+    if kind:
+        # the reference allocates dim*dim = 9 planes per block and fills the symmetric 6: NaN the other 3
+        pav = np.ascontiguousarray(np.concatenate([pav, np.full((NE, vd, 3, Q3), np.nan)], axis=2))
     rng = np.random.default_rng(3)
     xE = rng.random((NE, vd, D3))
     y0 = rng.random((NE, vd, D3))
@@ -103,7 +106,7 @@ def test_vector_integrator_seam_with_per_component_data(name):
     for k in range(vd):
         ys = dev(np.ascontiguousarray(y0[:, k, :]))
         xs = dev(np.ascontiguousarray(xE[:, k, :]))
-        pk = dev(np.ascontiguousarray(pav[:, k]))
+        pk = dev(np.ascontiguousarray(pav[:, k, :nc]))
         if kind:
             capi.call("mfem_amd_pa_diffusion_apply_3d", D, Q, NE, 1, B, G, ptr(pk), ptr(xs), ptr(ys), None)
         else:
@@ -122,7 +125,7 @@ def test_vector_integrator_seam_with_per_component_data(name):
 @pytest.mark.parametrize("name", ["cart3_bp3_p2", "cart2_bp1_p3", "toroid-hex_diff_p2"])
 @pytest.mark.parametrize("byvdim", [0, 1])
 def test_constrained_vector_operator_and_pcg(name, byvdim):
-    """ConstrainedOperator on a vector space with component-dependent essential dofs, and the fused PCG:
+    """ConstrainedOperator on a vector space (essential dofs on every component), and the fused PCG:
     the vector system is block diagonal, so with a per-component Jacobi the solve of (b, b/2, 2b) stops
     at the scalar solve's iteration and returns (X, X/2, 2X)."""
     from gpu_helpers import DeviceOperator, dev, host, ptr, zeros

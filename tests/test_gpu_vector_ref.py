@@ -1,0 +1,78 @@
+"""-m gpu: vector H1 spaces (CEED BP2/BP4/BP6) against the reference's OWN outputs
+(tests/golden/vec/*.npz from oracle/ref_dump_vec.cpp: VectorMassIntegrator / VectorDiffusionIntegrator,
+AssemblyLevel::PARTIAL, vdim = 3, byVDIM as tests/benchmarks/bench_ceed.cpp:47 and byNODES).
+Bars: data movement bit-exact, operator action 1e-12 relative, identical CG iteration counts."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from test_oracle_vector import CASES, load_vec, rel          # noqa: E402
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_vector_path_matches_reference(name):
+    from gpu_helpers import dev, hB, host, ptr, zeros
+    from mfem_amd import capi
+    capi.call("mfem_amd_init", 0)
+    c = load_vec(name)
+    kind, D, Q, NE, nd, vd, bv = c["kind"], c["D1D"], c["Q1D"], c["NE"], c["ndofs"], c["vdim"], c["byvdim"]
+    D3, Q3, n = D**3, Q**3, nd*vd
+    B, G = hB(c["B"]), hB(c["G"])
+    gm, off, ind = dev(c["gather_map"], np.int32), dev(c["offsets"], np.int32), dev(c["indices"], np.int32)
+    x = dev(c["x"])
+    # ElementRestriction::Mult with vdim: bit-exact
+    xE = zeros(NE*D3*vd)
+    capi.call("mfem_amd_restrict_gather_vdim", NE*D3, D3, vd, bv, nd, ptr(gm), ptr(x), ptr(xE), None)
+    assert np.array_equal(host(xE), c["xE"])
+    # the integrator seam on the reference's own pa_data (9-plane blocks per component / shared mass field)
+    pa_ref = dev(c["pa_data"])
+    yE = zeros(NE*D3*vd)
+    if kind:
+        capi.call("mfem_amd_pa_vector_diffusion_apply_3d", D, Q, NE, vd, c["coeff_vdim"], B, G, ptr(pa_ref), ptr(xE), ptr(yE), None)
+    else:
+        capi.call("mfem_amd_pa_vector_mass_apply_3d", D, Q, NE, vd, c["coeff_vdim"], B, ptr(pa_ref), ptr(xE), ptr(yE), None)
+    assert rel(host(yE), c["yE"]) < 1e-12
+    # fused L->L with ONE copy of the scalar operator's data, both layouts
+    pa_s = np.ascontiguousarray(c["pa_data"].reshape(NE, vd, 9, Q3)[:, 0, :6]) if kind else c["pa_data"]
+    pa0 = dev(pa_s)
+    layouts = [(0, pa0)]
+    if capi.lib.mfem_amd_has_specialization(kind, D, Q):
+        blk = zeros(capi.lib.mfem_amd_pa_data_size(kind, 1, Q, NE))
+        capi.call("mfem_amd_pa_data_to_blocked", kind, Q, NE, ptr(pa0), ptr(blk), None)
+        layouts.append((1, blk))
+    ess = np.asarray(c["ess_tdof"], np.int32)
+    ess_d = dev(ess, np.int32)
+    marker = zeros(n, torch.uint8)
+    capi.call("mfem_amd_set_marker", len(ess), ptr(ess_d), ptr(marker), None)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    for layout, pa in layouts:
+        yE2, y = zeros(NE*D3*vd), zeros(n)
+        capi.call("mfem_amd_pa_apply_L2E_vdim", kind, layout, D, Q, NE, vd, bv, nd, B, G, ptr(pa), 0, ptr(gm), None, ptr(x), ptr(yE2), None)
+        capi.call("mfem_amd_restrict_scatter_vdim", nd, D3, vd, bv, ptr(off), ptr(ind), ptr(yE2), ptr(y), 0, 0, None)
+        assert rel(host(yE2), c["yE"]) < 1e-12
+        assert rel(host(y), c["y"]) < 1e-12
+        # ConstrainedOperator + Jacobi-PCG + bench_ceed's plain CG (32 iterations at most)
+        op = capi.PaOperator(kind, layout, D, Q, NE, nd, vp(B), vp(G), ptr(pa), ptr(gm), None, ptr(off), ptr(ind),
+                             len(ess), ptr(ess_d), ptr(marker), ptr(yE2), vd, bv, 0)
+        yc = zeros(n)
+        capi.call("mfem_amd_pa_constrained_mult", C.byref(op), ptr(x), ptr(yc), None)
+        assert rel(host(yc), c["y_constrained"]) < 1e-12
+        dinv = 1.0/np.asarray(c["diag"])
+        dinv[ess] = 1.0
+        dinv_d, b_d = dev(dinv), dev(c["B_rhs"])
+        ws = zeros(capi.lib.mfem_amd_pcg_workspace_bytes(n, 2000), torch.uint8)
+        X, res = zeros(n), capi.PcgResult()
+        capi.call("mfem_amd_pcg_pa", C.byref(op), ptr(dinv_d), ptr(b_d), ptr(X), 1e-10 if kind == 0 else 1e-6, 0.0, 2000, 1,
+                  ptr(ws), C.byref(res), None, None)
+        assert (res.iterations, res.converged) == (c["cg_iters"], c["cg_converged"])
+        assert rel(host(X), c["X"]) < 1e-9
+        X2, res2 = zeros(n), capi.PcgResult()
+        capi.call("mfem_amd_pcg_pa", C.byref(op), None, ptr(b_d), ptr(X2), 1e-12, 0.0, 32, 4, ptr(ws), C.byref(res2), None, None)
+        # rel tol 1e-12 on sqrt((r,r)) is a 1e-24 reduction: where CG converges before the 32-iteration cap the
+        # last decision sits in the dot products' rounding (the reference sums sequentially): +-1
+        assert abs(res2.iterations - c["cg32_iters"]) <= (1 if c["cg32_iters"] < 32 else 0)
+        assert rel(host(X2), c["X_cg32"]) < 1e-9
