@@ -27,7 +27,7 @@ int main(int argc, char *argv[])
    int bp = 3, p = 4, N = 12;
    const char *device_config = "hip";
    OptionsParser args(argc, argv);
-   args.AddOption(&bp, "-bp", "--bake-off-problem", "1 (mass), 3 (diffusion, q=p+2), 5 (diffusion, GLL q=p+1).");
+   args.AddOption(&bp, "-bp", "--bake-off-problem", "1 (mass), 3 (diffusion, q=p+2), 5 (diffusion, GLL q=p+1); 2, 4, 6: the vector (vdim = 3) versions.");
    args.AddOption(&p, "-p", "--order", "Polynomial degree (0: sweep p = 1..8).");
    args.AddOption(&N, "-n", "--elements", "Elements per direction (0: 48/p, the known-answer table of BASELINE.md).");
    args.AddOption(&reps, "-reps", "--repetitions", "Timed operator applications.");
@@ -39,7 +39,7 @@ int main(int argc, char *argv[])
    args.AddOption(&device_config, "-d", "--device", "Device configuration string.");
    args.Parse();
    if (!args.Good()) { args.PrintUsage(std::cout); return 1; }
-   MFEM_VERIFY(bp == 1 || bp == 3 || bp == 5, "bp must be 1, 3 or 5");
+   MFEM_VERIFY(bp >= 1 && bp <= 6, "bp must be 1..6");
    Device device(device_config);
    for (int q = (p ? p : 1); q <= (p ? p : 8); q++) { run_case(bp, q, N ? N : 48/q); }
    return 0;
@@ -47,11 +47,13 @@ int main(int argc, char *argv[])
 
 static void run_case(int bp, int p, int N)
 {
-   const bool GLL = bp == 5;
+   // bench_ceed.cpp:141-156: BP1/2 mass, BP3/4 diffusion q=p+2, BP5/6 diffusion GLL q=p+1; even = VDIM 3, byVDIM (:47)
+   const bool GLL = bp >= 5, mass = bp <= 2;
+   const int VDIM = (bp % 2 == 0) ? 3 : 1;
    double t0 = now();
    Mesh mesh = Mesh::MakeCartesian3D(N, N, N, Element::HEXAHEDRON, 1.0, 1.0, 1.0, !lex);
    H1_FECollection fec(p, 3, BasisType::GaussLobatto);
-   FiniteElementSpace fes(&mesh, &fec);
+   FiniteElementSpace fes(&mesh, &fec, VDIM, VDIM == 3 ? Ordering::byVDIM : Ordering::byNODES);
    IntegrationRules irs(0, GLL ? Quadrature1D::GaussLobatto : Quadrature1D::GaussLegendre);
    const IntegrationRule *ir = &irs.Get(Geometry::CUBE, 2*p + (GLL ? -1 : 3));
    ConstantCoefficient one(1.0);
@@ -59,8 +61,10 @@ static void run_case(int bp, int p, int N)
    GridFunction x(&fes), y(&fes);
    BilinearForm a(&fes);
    a.SetAssemblyLevel(AssemblyLevel::PARTIAL);
-   if (bp == 1) { a.AddDomainIntegrator(new MassIntegrator(one, ir)); }
-   else { a.AddDomainIntegrator(new DiffusionIntegrator(one, ir)); }
+   if (VDIM == 1 && mass) { a.AddDomainIntegrator(new MassIntegrator(one, ir)); }
+   else if (VDIM == 1) { a.AddDomainIntegrator(new DiffusionIntegrator(one, ir)); }
+   else if (mass) { a.AddDomainIntegrator(new VectorMassIntegrator(one, ir)); }
+   else { a.AddDomainIntegrator(new VectorDiffusionIntegrator(one, ir)); }
    a.Assemble();
    double t_setup = now() - t0;
 
@@ -76,7 +80,8 @@ static void run_case(int bp, int p, int N)
    const double t_apply = (now() - t0)/reps;
    // algorithmic bytes of one L->L apply: NE*(C*Q^3*8 + 2*D^3*4) + N_L*20
    const double D1 = p + 1, Q1 = ir->n1d, NE = (double)N*N*N;
-   const double bytes_apply = NE*((bp == 1 ? 1 : 6)*Q1*Q1*Q1*8 + 2*D1*D1*D1*4) + 20.0*dofs;
+   // vector spaces: q-data, gather_map and indices once per element; x, y per vdof; offsets per scalar dof
+   const double bytes_apply = NE*((mass ? 1 : 6)*Q1*Q1*Q1*8 + 2*D1*D1*D1*4) + 16.0*dofs + 4.0*dofs/VDIM;
    printf("{\"phase\": \"kernel\", \"bp\": %d, \"p\": %d, \"N\": %d, \"dofs\": %d, \"norm_Ax\": %.15e, \"ms_per_apply\": %.6f, "
           "\"MDof/s\": %.3f, \"GB/s\": %.1f, \"hbm_frac\": %.4f, \"setup_s\": %.3f}\n", bp, p, N, dofs, ynorm, t_apply*1e3,
           1e-6*dofs/t_apply, 1e-9*bytes_apply/t_apply, 1e-9*bytes_apply/t_apply/8000.0, t_setup);
@@ -86,7 +91,10 @@ static void run_case(int bp, int p, int N)
    ess_bdr = 1;
    fes.GetEssentialTrueDofs(ess_bdr, ess_tdof_list);
    LinearForm b(&fes);
-   b.AddDomainIntegrator(new DomainLFIntegrator(one));
+   Vector uvec(3); uvec = 1.0; uvec /= uvec.Norml2();
+   VectorConstantCoefficient unit_vec(uvec);
+   if (VDIM == 1) { b.AddDomainIntegrator(new DomainLFIntegrator(one)); }
+   else { b.AddDomainIntegrator(new VectorDomainLFIntegrator(unit_vec)); }
    b.UseFastAssembly(true);
    b.Assemble();
    x = 0.0;

@@ -222,7 +222,8 @@ int mfem_amd_pa_apply_L2E_vdim(int kind, int pa_layout, int D1D, int Q1D, int64_
  * fem/integ/bilininteg_vecdiffusion_pa.hpp:108-170): yE += A xE on (D,D,D,vdim,NE) E-vectors;
  * D is the reference's pa_data (Q,Q,Q,9,vdim,NE): dim*dim planes allocated per component, the
  * symmetric six filled and read (bilininteg_vecdiffusion_pa.cpp:133-134,228-290).
- * coeff_vdim 1 or vdim; matrix coefficients (vdim^2) are rejected. */
+ * coeff_vdim 1 or vdim; matrix coefficients (vdim^2) are rejected.  Extension: coeff_vdim = 0
+ * takes the SCALAR integrator's (Q,Q,Q,6,NE) data, shared by all components. */
 int mfem_amd_pa_vector_diffusion_apply_3d(int D1D, int Q1D, int64_t ne, int vdim, int coeff_vdim,
                                           const double *B, const double *G, const double *D,
                                           const double *xE, double *yE, void *stream);
@@ -231,6 +232,14 @@ int mfem_amd_pa_vector_diffusion_apply_3d(int D1D, int Q1D, int64_t ne, int vdim
 int mfem_amd_pa_vector_mass_apply_3d(int D1D, int Q1D, int64_t ne, int vdim, int coeff_vdim,
                                      const double *B, const double *D, const double *xE,
                                      double *yE, void *stream);
+
+/* y[vdof(i,c)] = scale[c]*x[i], i < ndofs, c < vdim (scale: HOST, vdim doubles, NULL = ones):
+ * spreads a scalar-space vector over the components of a vector space -- the diagonal of a
+ * vector integrator with a scalar coefficient (PAVectorDiffusionDiagonal3D,
+ * fem/integ/bilininteg_vecdiffusion_pa.cpp) and VectorDomainLFIntegrator with a constant vector
+ * coefficient (fem/lininteg.cpp) are the scalar results per component. */
+int mfem_amd_vec_replicate_vdim(int64_t ndofs, int vdim, int byvdim, const double *scale,
+                                const double *x, double *y, void *stream);
 
 /* Problem description for mfem_amd_pcg_pa (all device pointers unless marked HOST). */
 typedef struct mfem_amd_pa_operator

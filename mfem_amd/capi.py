@@ -76,6 +76,7 @@ _SIGS = {
     "mfem_amd_pa_apply_L2E_vdim": (cint, [cint, cint, cint, cint, i64, cint, cint, i64, _hd, _hd, vp, i64, vp, vp, vp, vp, vp]),
     "mfem_amd_pa_vector_diffusion_apply_3d": (cint, [cint, cint, i64, cint, cint, _hd, _hd, vp, vp, vp, vp]),
     "mfem_amd_pa_vector_mass_apply_3d": (cint, [cint, cint, i64, cint, cint, _hd, vp, vp, vp, vp]),
+    "mfem_amd_vec_replicate_vdim": (cint, [i64, cint, cint, vp, vp, vp, vp]),
     "mfem_amd_set_marker": (cint, [i64, vp, vp, vp]),
     "mfem_amd_mask_gather_map": (cint, [i64, vp, vp, vp, vp]),
     "mfem_amd_set_subvector": (cint, [i64, vp, vp, dbl, vp, vp]),

@@ -164,7 +164,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
          }
       }
    };
-   auto load_xv = [&](const int64_t e)
+   auto load_xv = [&](const int64_t e, const int cc = 0)
    {
       if (ABL & 8)
       {
@@ -173,7 +173,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
          return;
       }
       const int64_t ec = e < elast ? e : elast;
-      const double *xe = x + (VEC ? ec*va.vd + comp : ec)*D3;
+      const double *xe = x + (VEC ? ec*va.vd + cc : ec)*D3;
 #pragma unroll
       for (int k = 0; k < NXV; k++)
       {
@@ -181,7 +181,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
          if (GATHER && VEC)
          {
             const int64_t g = gi[k] >= 0 ? gi[k] : 0;
-            const int64_t idx = va.byvdim ? g*va.vd + comp : g + comp*va.ndofs;
+            const int64_t idx = va.byvdim ? g*va.vd + cc : g + cc*va.ndofs;
             const double v = x[idx];
             const bool masked = va.marker ? (va.marker[idx] != 0) : false;
             xv[k] = (gi[k] >= 0 && !masked) ? v : 0.0;
@@ -283,11 +283,9 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
       asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
       for (comp = 0; comp < (VEC ? va.vd : 1); comp++)
       {
-         if (VEC && comp > 0)
-         {
-            load_xv(e);
-            if (va.d_comp_stride) { load_O(e, bt); }
-         }
+         // VEC: the x values of the next component are requested right after this one's have been
+         // staged (below), so only the first gather of a workgroup is waited for
+         if (VEC && comp > 0 && va.d_comp_stride) { load_O(e, bt); }
 
 #pragma unroll
          for (int k = 0; k < NXV; k++)
@@ -296,6 +294,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
             if (i < D3) { sX[RB ? (i/D)*DP + i % D : i] = xv[k]; }
          }
          if (PERSIST) { load_gi(en); }       // next batch's gather indices: in flight from here
+         if (VEC && comp + 1 < va.vd) { load_xv(e, comp + 1); }
          __syncthreads();
          if (ABL & 1)
          {
@@ -1152,6 +1151,12 @@ extern "C" int mfem_amd_pa_vector_diffusion_apply_3d(int D1D, int Q1D, int64_t n
                                                      const double *B, const double *G, const double *D,
                                                      const double *xE, double *yE, void *stream)
 {
+   if (coeff_vdim == 0)
+   {
+      // extension: D is the SCALAR integrator's (Q,Q,Q,6,NE), shared by all components
+      VecArgs vs = {vdim, 0, 0, nullptr, 0, 0};
+      return run_apply_vec<1, false, true, false>(D1D, Q1D, ne, B, G, D, xE, nullptr, yE, vs, as_stream(stream));
+   }
    MFA_REQUIRE(coeff_vdim == 1 || coeff_vdim == vdim,
                "pa_vector_diffusion_apply_3d: scalar and vector coefficients only (coeff_vdim = %d, vdim = %d); "
                "matrix coefficients are not built", coeff_vdim, vdim);

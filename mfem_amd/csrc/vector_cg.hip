@@ -304,6 +304,33 @@ extern "C" int mfem_amd_jacobi_setup(int64_t n, const double *diag, double dampi
    return 0;
 }
 
+// y[vdof(i,c)] = scale[c]*x[i]: a scalar-space vector spread over the components of a vector space
+struct RepScale { double s[16]; };
+__global__ void __launch_bounds__(256)
+k_replicate_vdim(const int64_t ndofs, const int vd, const int byvdim, const RepScale sc,
+                 const double *__restrict__ x, double *__restrict__ y)
+{
+   const int64_t n = ndofs*vd;
+   for (int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x; i < n; i += (int64_t)gridDim.x*256)
+   {
+      const int64_t dof = byvdim ? i/vd : i % ndofs;
+      const int c = (int)(byvdim ? i % vd : i/ndofs);
+      y[i] = sc.s[c]*x[dof];
+   }
+}
+
+extern "C" int mfem_amd_vec_replicate_vdim(int64_t ndofs, int vdim, int byvdim, const double *scale,
+                                           const double *x, double *y, void *stream)
+{
+   if (ndofs == 0) { return 0; }
+   MFA_REQUIRE(ndofs > 0 && vdim >= 1 && vdim <= 16 && x && y, "vec_replicate_vdim: bad arguments (vdim must be in 1..16)");
+   RepScale sc;
+   for (int c = 0; c < 16; c++) { sc.s[c] = (scale && c < vdim) ? scale[c] : 1.0; }
+   k_replicate_vdim<<<dim3(stream_grid(ndofs*vdim)), dim3(256), 0, as_stream(stream)>>>(ndofs, vdim, byvdim ? 1 : 0, sc, x, y);
+   MFA_CHECK_LAUNCH("k_replicate_vdim");
+   return 0;
+}
+
 extern "C" int mfem_amd_jacobi_apply(int64_t n, const double *dinv, const double *r, double *z,
                                      void *stream)
 {

@@ -277,21 +277,34 @@ void ElementRestriction::Mult(const Vector &x, Vector &y) const
 }
 void ElementRestriction::MultTranspose(const Vector &x, Vector &y) const
 {
-   MFEM_VERIFY(vdim == 1, "mfem_amd: the transpose restriction is built for scalar spaces");
    MFEM_VERIFY(x.Size() == Height(), "ElementRestriction::MultTranspose: wrong input size");
    y.SetSize(Width());
-   MFEM_AMD_CALL(mfem_amd_restrict_scatter(ndofs, offsets.Read(), indices.Read(), x.Read(), y.Write(), 0, 0, nullptr));
+   if (vdim == 1) { MFEM_AMD_CALL(mfem_amd_restrict_scatter(ndofs, offsets.Read(), indices.Read(), x.Read(), y.Write(), 0, 0, nullptr)); }
+   else
+   {
+      MFEM_AMD_CALL(mfem_amd_restrict_scatter_vdim(ndofs, dof, vdim, byvdim ? 1 : 0, offsets.Read(), indices.Read(), x.Read(),
+                                                   y.Write(), 0, 0, nullptr));
+   }
 }
 void ElementRestriction::AddMultTranspose(const Vector &x, Vector &y, const real_t a) const
 {
-   MFEM_VERIFY(vdim == 1 && a == 1.0, "mfem_amd: AddMultTranspose is built for scalar spaces and a = 1");
-   MFEM_AMD_CALL(mfem_amd_restrict_scatter(ndofs, offsets.Read(), indices.Read(), x.Read(), y.ReadWrite(), 1, 0, nullptr));
+   MFEM_VERIFY(a == 1.0, "mfem_amd: AddMultTranspose is built for a = 1");
+   if (vdim == 1) { MFEM_AMD_CALL(mfem_amd_restrict_scatter(ndofs, offsets.Read(), indices.Read(), x.Read(), y.ReadWrite(), 1, 0, nullptr)); }
+   else
+   {
+      MFEM_AMD_CALL(mfem_amd_restrict_scatter_vdim(ndofs, dof, vdim, byvdim ? 1 : 0, offsets.Read(), indices.Read(), x.Read(),
+                                                   y.ReadWrite(), 1, 0, nullptr));
+   }
 }
 void ElementRestriction::AbsMultTranspose(const Vector &x, Vector &y) const
 {
-   MFEM_VERIFY(vdim == 1, "mfem_amd: the transpose restriction is built for scalar spaces");
    y.SetSize(Width());
-   MFEM_AMD_CALL(mfem_amd_restrict_scatter(ndofs, offsets.Read(), indices.Read(), x.Read(), y.Write(), 0, 1, nullptr));
+   if (vdim == 1) { MFEM_AMD_CALL(mfem_amd_restrict_scatter(ndofs, offsets.Read(), indices.Read(), x.Read(), y.Write(), 0, 1, nullptr)); }
+   else
+   {
+      MFEM_AMD_CALL(mfem_amd_restrict_scatter_vdim(ndofs, dof, vdim, byvdim ? 1 : 0, offsets.Read(), indices.Read(), x.Read(),
+                                                   y.Write(), 0, 1, nullptr));
+   }
 }
 
 // ---- GridFunction -----------------------------------------------------------------------
@@ -418,28 +431,44 @@ void eval_coefficient(Mesh &mesh, const IntegrationRule &ir, Coefficient *Q, Vec
 // ---- LinearForm (fem/linearform.cpp Assemble; device kernel of lininteg_domain.cpp:22-59) --
 void LinearForm::Assemble()
 {
-   MFEM_VERIFY(fes->GetVDim() == 1, "mfem_amd: scalar linear forms only");
    Vector::operator=(0.0);
    const FiniteElement *fe = fes->GetTypicalFE();
    const ElementRestriction *R = fes->GetElementRestriction(ElementDofOrdering::LEXICOGRAPHIC);
-   const int NE = fes->GetNE();
-   Vector bE(R->Height());
+   const int NE = fes->GetNE(), vd = fes->GetVDim(), nd = fe->GetDof();
+   Vector bE((int64_t)NE*nd);
+   ConstantCoefficient one(1.0);
    for (LinearFormIntegrator *lfi : domain_integs)
    {
       DomainLFIntegrator *dlf = dynamic_cast<DomainLFIntegrator*>(lfi);
-      MFEM_VERIFY(dlf, "mfem_amd: only DomainLFIntegrator");
-      const IntegrationRule &ir = dlf->IntRule ? *dlf->IntRule : IntRules.Get(Geometry::CUBE, dlf->oa*fe->GetOrder() + dlf->ob);
+      VectorDomainLFIntegrator *vlf = dynamic_cast<VectorDomainLFIntegrator*>(lfi);
+      MFEM_VERIFY(dlf || vlf, "mfem_amd: only DomainLFIntegrator and VectorDomainLFIntegrator");
+      MFEM_VERIFY(dlf ? vd == 1 : vlf->Q.GetVDim() == vd, "the integrator does not match the space's vdim");
+      Vector fvec;
+      if (vlf) { MFEM_VERIFY(vlf->Q.IsConstant(fvec), "mfem_amd: VectorDomainLFIntegrator is built for constant coefficients"); }
+      // VectorDomainLFIntegrator's default rule: order 2p (fem/lininteg.cpp), as DomainLFIntegrator(a = 2, b = 0)
+      const IntegrationRule *irp = dlf ? dlf->IntRule : vlf->IntRule;
+      const IntegrationRule &ir = irp ? *irp : IntRules.Get(Geometry::CUBE, dlf ? dlf->oa*fe->GetOrder() + dlf->ob : 2*fe->GetOrder());
       const DofToQuad &maps = fe->GetDofToQuad(ir, DofToQuad::TENSOR);
       NodesAtRule g; prepare_nodes(*fes->GetMesh(), ir, g);
       Vector C; int const_c;
-      eval_coefficient(*fes->GetMesh(), ir, &dlf->Q, C, const_c);
+      eval_coefficient(*fes->GetMesh(), ir, dlf ? &dlf->Q : &one, C, const_c);
       const int Q1 = maps.nqpt;
       Vector F(Q1*Q1*Q1*NE);       // W * f * detJ at the points = a mass setup with coefficient f
       MFEM_AMD_CALL(mfem_amd_pa_setup_from_nodes_3d(0, g.Dn, Q1, 1, NE, g.Bn.data(), g.Gn.data(), ir.GetWeights().Read(),
                                                     g.nodesE.Read(), C.Read(), const_c, 0, F.Write(), nullptr, nullptr));
       bE = 0.0;
       MFEM_AMD_CALL(mfem_amd_domain_lf_3d(maps.ndof, Q1, NE, maps.B.HostRead(), F.Read(), bE.ReadWrite(), nullptr));
-      R->AddMultTranspose(bE, *this);
+      if (dlf) { R->AddMultTranspose(bE, *this); }
+      else
+      {
+         // component c of the vector form = f_c x the scalar form with f = 1
+         const int ndofs = fes->GetNDofs();
+         Vector bS(ndofs), bV(Size());
+         MFEM_AMD_CALL(mfem_amd_restrict_scatter(ndofs, R->Offsets().Read(), R->Indices().Read(), bE.Read(), bS.Write(), 0, 0, nullptr));
+         MFEM_AMD_CALL(mfem_amd_vec_replicate_vdim(ndofs, vd, fes->GetOrdering() == Ordering::byVDIM ? 1 : 0, fvec.HostRead(),
+                                                   bS.Read(), bV.Write(), nullptr));
+         *this += bV;
+      }
    }
 }
 
@@ -461,7 +490,8 @@ const IntegrationRule &MassIntegrator::GetRule(const FiniteElement &trial_fe, co
 // the geometric factors fused in: nodes -> pa_data in one kernel, J is never stored.
 void BilinearFormIntegrator::SetupPA(const FiniteElementSpace &fes, int kind_, Coefficient *Q, const IntegrationRule &ir)
 {
-   MFEM_VERIFY(fes.GetVDim() == 1, "mfem_amd: scalar spaces only");
+   MFEM_VERIFY(vector_integrator || fes.GetVDim() == 1, "mfem_amd: a scalar integrator needs a scalar space (use the Vector* integrators)");
+   vdim = fes.GetVDim();
    Mesh *mesh = fes.GetMesh();
    const FiniteElement *fe = fes.GetTypicalFE();
    kind = kind_; ne = fes.GetNE();
@@ -526,6 +556,38 @@ void MassIntegrator::AssembleDiagonalPA(Vector &diag)
                                           diag.ReadWrite(), nullptr));
 }
 
+// Vector integrators with a scalar coefficient (fem/integ/bilininteg_vecdiffusion_pa.cpp:71-290,
+// bilininteg_vecmass_pa.cpp:20-160): the scalar operator's pa_data, stored ONCE (the reference stores
+// vdim identical copies for diffusion), applied to every component.
+void VectorDiffusionIntegrator::AssemblePA(const FiniteElementSpace &fes)
+{
+   const FiniteElement &el = *fes.GetTypicalFE();
+   SetupPA(fes, 1, Q, IntRule ? *IntRule : DiffusionIntegrator::GetRule(el, el));
+}
+void VectorDiffusionIntegrator::AddMultPA(const Vector &x, Vector &y) const
+{
+   MFEM_VERIFY(maps, "AssemblePA must be called first");
+   MFEM_AMD_CALL(mfem_amd_pa_vector_diffusion_apply_3d(dofs1D, quad1D, ne, vdim, 0, maps->B.HostRead(), maps->G.HostRead(),
+                                                       MFEMLayoutData().Read(), x.Read(), y.ReadWrite(), nullptr));
+}
+void VectorDiffusionIntegrator::AssembleDiagonalPA(Vector &)
+{ MFEM_ABORT("mfem_amd: the E-vector diagonal of a vector integrator is not built; use BilinearForm::AssembleDiagonal"); }
+void VectorMassIntegrator::AssemblePA(const FiniteElementSpace &fes)
+{
+   const FiniteElement &el = *fes.GetTypicalFE();
+   fes.GetMesh()->EnsureNodes();
+   const int nodes_order = fes.GetMesh()->GetNodalFESpace()->GetMaxElementOrder();
+   SetupPA(fes, 0, Q, IntRule ? *IntRule : MassIntegrator::GetRule(el, el, nodes_order));
+}
+void VectorMassIntegrator::AddMultPA(const Vector &x, Vector &y) const
+{
+   MFEM_VERIFY(maps, "AssemblePA must be called first");
+   MFEM_AMD_CALL(mfem_amd_pa_vector_mass_apply_3d(dofs1D, quad1D, ne, vdim, 1, maps->B.HostRead(), MFEMLayoutData().Read(),
+                                                  x.Read(), y.ReadWrite(), nullptr));
+}
+void VectorMassIntegrator::AssembleDiagonalPA(Vector &)
+{ MFEM_ABORT("mfem_amd: the E-vector diagonal of a vector integrator is not built; use BilinearForm::AssembleDiagonal"); }
+
 // ---- PABilinearFormExtension (fem/bilinearform_ext.cpp:256-564) -------------------------
 PABilinearFormExtension::PABilinearFormExtension(BilinearForm *form)
    : Operator(form->FESpace()->GetVSize()), a(form), fes(form->FESpace()) {}
@@ -544,7 +606,17 @@ void PABilinearFormExtension::Mult(const Vector &x, Vector &y) const
 {
    MFEM_VERIFY(elem_restrict, "BilinearForm::Assemble must be called first");
    MFEM_VERIFY(x.Size() == Width() && y.Size() == Height(), "incompatible sizes");
-   if (const BilinearFormIntegrator *bfi = SingleIntegrator())
+   const int vd = fes->GetVDim();
+   if (vd > 1)
+   {
+      const BilinearFormIntegrator *bfi = SingleIntegrator();
+      MFEM_VERIFY(bfi && bfi->vector_integrator, "mfem_amd: a vector space takes exactly one Vector{Mass,Diffusion}Integrator");
+      MFEM_AMD_CALL(mfem_amd_pa_apply_L2E_vdim(bfi->kind, bfi->pa_layout, bfi->dofs1D, bfi->quad1D, bfi->ne, vd,
+                                               fes->GetOrdering() == Ordering::byVDIM ? 1 : 0, fes->GetNDofs(),
+                                               bfi->maps->B.HostRead(), bfi->maps->G.HostRead(), bfi->pa_data.Read(), 0,
+                                               elem_restrict->GatherMap().Read(), nullptr, x.Read(), localY.Write(), nullptr));
+   }
+   else if (const BilinearFormIntegrator *bfi = SingleIntegrator())
    {
       // gather fused into the element kernel: no localX, no memset of localY
       MFEM_AMD_CALL(mfem_amd_pa_apply_L2E(bfi->kind, bfi->pa_layout, bfi->dofs1D, bfi->quad1D, bfi->ne,
@@ -563,6 +635,32 @@ void PABilinearFormExtension::AssembleDiagonal(Vector &diag) const
 {
    MFEM_VERIFY(elem_restrict, "BilinearForm::Assemble must be called first");
    diag.SetSize(Height());
+   const int vd = fes->GetVDim();
+   if (vd > 1)
+   {
+      // scalar coefficient: every component carries the scalar operator's diagonal
+      // (PAVectorDiffusionDiagonal3D loops the scalar kernel over the components)
+      const BilinearFormIntegrator *bfi = SingleIntegrator();
+      MFEM_VERIFY(bfi && bfi->vector_integrator, "mfem_amd: a vector space takes exactly one Vector{Mass,Diffusion}Integrator");
+      const int ndofs = fes->GetNDofs(), nd = fes->GetTypicalFE()->GetDof();
+      Vector dE((int64_t)bfi->ne*nd), dS(ndofs);
+      dE = 0.0;
+      if (bfi->kind)
+      {
+         MFEM_AMD_CALL(mfem_amd_pa_diffusion_diag_3d(bfi->dofs1D, bfi->quad1D, bfi->ne, 1, bfi->maps->B.HostRead(), bfi->maps->G.HostRead(),
+                                                     bfi->pa_data.Read(), bfi->pa_layout, dE.ReadWrite(), nullptr));
+      }
+      else
+      {
+         MFEM_AMD_CALL(mfem_amd_pa_mass_diag_3d(bfi->dofs1D, bfi->quad1D, bfi->ne, bfi->maps->B.HostRead(), bfi->pa_data.Read(),
+                                                bfi->pa_layout, dE.ReadWrite(), nullptr));
+      }
+      MFEM_AMD_CALL(mfem_amd_restrict_scatter(ndofs, elem_restrict->Offsets().Read(), elem_restrict->Indices().Read(), dE.Read(),
+                                              dS.Write(), 0, 1, nullptr));
+      MFEM_AMD_CALL(mfem_amd_vec_replicate_vdim(ndofs, vd, fes->GetOrdering() == Ordering::byVDIM ? 1 : 0, nullptr, dS.Read(),
+                                                diag.Write(), nullptr));
+      return;
+   }
    localY = 0.0;
    for (BilinearFormIntegrator *bfi : a->domain_integs) { bfi->AssembleDiagonalPA(localY); }
    elem_restrict->AbsMultTranspose(localY, diag);       // bilinearform_ext.cpp:413-418
@@ -631,7 +729,12 @@ bool PABilinearFormExtension::FillOperator(mfem_amd_pa_operator &op) const
    std::memset(&op, 0, sizeof(op));
    const ElementRestriction *R = elem_restrict;
    op.kind = bfi->kind; op.pa_layout = bfi->pa_layout; op.D1D = bfi->dofs1D; op.Q1D = bfi->quad1D;
-   op.ne = bfi->ne; op.ndofs = Height();
+   op.ne = bfi->ne; op.ndofs = fes->GetNDofs();
+   if (fes->GetVDim() > 1)
+   {
+      if (!bfi->vector_integrator) { return false; }
+      op.vdim = fes->GetVDim(); op.byvdim = fes->GetOrdering() == Ordering::byVDIM ? 1 : 0; op.pa_comp_stride = 0;
+   }
    op.B = bfi->maps->B.HostRead(); op.G = bfi->maps->G.HostRead();
    op.pa_data = bfi->pa_data.Read();
    op.gather_map = R->GatherMap().Read(); op.masked_gather_map = op.gather_map;
@@ -654,9 +757,9 @@ ConstrainedOperator::ConstrainedOperator(Operator *A_, const Array<int> &list, b
       marker.SetSize(height); marker = (unsigned char)0;
       marker.Read();
       const int ness = constraint_list.Size();
-      if (ness)
+      if (ness) { MFEM_AMD_CALL(mfem_amd_set_marker(ness, constraint_list.Read(), marker.ReadWrite(), nullptr)); }
+      if (ness && cop.vdim == 0)         // vector spaces apply the marker in the gather instead
       {
-         MFEM_AMD_CALL(mfem_amd_set_marker(ness, constraint_list.Read(), marker.ReadWrite(), nullptr));
          const ElementRestriction *R = ext->GetElementRestriction();
          masked_gather.SetSize(R->GatherMap().Size());
          MFEM_AMD_CALL(mfem_amd_mask_gather_map(R->GatherMap().Size(), R->GatherMap().Read(), marker.Read(),

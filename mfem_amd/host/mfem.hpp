@@ -495,6 +495,26 @@ public:
    real_t EvalAt(const Vector &) const override { return constant; }
    bool IsConstant(real_t &c) const override { c = constant; return true; }
 };
+/// fem/coefficient.hpp VectorCoefficient / VectorConstantCoefficient (the constant one is what the
+/// bake-off right-hand sides use, tests/benchmarks/bench_ceed.cpp:54)
+class VectorCoefficient
+{
+protected:
+   int vdim;
+public:
+   explicit VectorCoefficient(int vd) : vdim(vd) {}
+   virtual ~VectorCoefficient() {}
+   int GetVDim() const { return vdim; }
+   virtual bool IsConstant(Vector &) const { return false; }
+};
+class VectorConstantCoefficient : public VectorCoefficient
+{
+   Vector vec;
+public:
+   explicit VectorConstantCoefficient(const Vector &v) : VectorCoefficient(v.Size()), vec(v) {}
+   const Vector &GetVec() const { return vec; }
+   bool IsConstant(Vector &v) const override { v = vec; return true; }
+};
 class FunctionCoefficient : public Coefficient
 {
    std::function<real_t(const Vector &)> F;
@@ -740,6 +760,14 @@ public:
    DomainLFIntegrator(Coefficient &QF, int a = 2, int b = 0) : Q(QF), oa(a), ob(b) {}
    DomainLFIntegrator(Coefficient &QF, const IntegrationRule *ir) : Q(QF), oa(1), ob(1), IntRule(ir) {}
 };
+/// (f, v) for a vector space (fem/lininteg.hpp VectorDomainLFIntegrator); constant f only.
+class VectorDomainLFIntegrator : public LinearFormIntegrator
+{
+public:
+   VectorCoefficient &Q; const IntegrationRule *IntRule = nullptr;
+   explicit VectorDomainLFIntegrator(VectorCoefficient &QF) : Q(QF) {}
+   VectorDomainLFIntegrator(VectorCoefficient &QF, const IntegrationRule *ir) : Q(QF), IntRule(ir) {}
+};
 class LinearForm : public Vector
 {
    FiniteElementSpace *fes; std::vector<LinearFormIntegrator*> domain_integs;
@@ -760,6 +788,8 @@ protected:
    const IntegrationRule *IntRule;
    // PA state (device)
    int kind = -1, dofs1D = 0, quad1D = 0, ne = 0, pa_layout = 1;
+   int vdim = 1;                         // components of the space (vector integrators)
+   bool vector_integrator = false;
    const DofToQuad *maps = nullptr;
    Vector pa_data;
    mutable Vector pa_data_mfem;          // MFEM-layout copy, made on the first E-vector AddMultPA
@@ -800,6 +830,30 @@ public:
    MassIntegrator(Coefficient &q, const IntegrationRule *ir = nullptr) : BilinearFormIntegrator(ir), Q(&q) {}
    /// order 2p + OrderW of the nodal transformation (fem/bilininteg.cpp:1450-1462)
    static const IntegrationRule &GetRule(const FiniteElement &trial_fe, const FiniteElement &test_fe, int nodes_order);
+   void AssemblePA(const FiniteElementSpace &fes) override;
+   void AddMultPA(const Vector &x, Vector &y) const override;
+   void AssembleDiagonalPA(Vector &diag) override;
+};
+
+/// fem/bilininteg.hpp VectorDiffusionIntegrator; PA in fem/integ/bilininteg_vecdiffusion_pa.cpp: the scalar
+/// operator on every component of a vector H1 space (scalar coefficient; CEED BP4/BP6).
+class VectorDiffusionIntegrator : public BilinearFormIntegrator
+{
+   Coefficient *Q;
+public:
+   VectorDiffusionIntegrator(const IntegrationRule *ir = nullptr) : BilinearFormIntegrator(ir), Q(nullptr) { vector_integrator = true; }
+   VectorDiffusionIntegrator(Coefficient &q, const IntegrationRule *ir = nullptr) : BilinearFormIntegrator(ir), Q(&q) { vector_integrator = true; }
+   void AssemblePA(const FiniteElementSpace &fes) override;
+   void AddMultPA(const Vector &x, Vector &y) const override;
+   void AssembleDiagonalPA(Vector &diag) override;
+};
+/// fem/bilininteg.hpp VectorMassIntegrator; PA in fem/integ/bilininteg_vecmass_pa.cpp (CEED BP2).
+class VectorMassIntegrator : public BilinearFormIntegrator
+{
+   Coefficient *Q;
+public:
+   VectorMassIntegrator(const IntegrationRule *ir = nullptr) : BilinearFormIntegrator(ir), Q(nullptr) { vector_integrator = true; }
+   VectorMassIntegrator(Coefficient &q, const IntegrationRule *ir = nullptr) : BilinearFormIntegrator(ir), Q(&q) { vector_integrator = true; }
    void AssemblePA(const FiniteElementSpace &fes) override;
    void AddMultPA(const Vector &x, Vector &y) const override;
    void AssembleDiagonalPA(Vector &diag) override;

@@ -75,6 +75,29 @@ def test_bakeoff_known_answers(bp):
         assert abs(prob[p]["norm_X"] - ref[p]["norm_X"]) <= 1e-8*ref[p]["norm_X"]
 
 
+ANCHORS_VEC = json.loads((ROOT / "tests" / "golden" / "baseline_anchors_vec.json").read_text())
+
+
+@pytest.mark.parametrize("bp", [2, 4, 6])
+def test_vector_bakeoff_known_answers(bp):
+    """BP2/BP4/BP6 (Vector{Mass,Diffusion}Integrator on a vdim = 3, byVDIM space) through the C++ API: |A x| for
+    x.Randomize(1) to 1e-12, Jacobi-PCG iterations and |X| against the reference's values
+    (oracle/ref_probe_vec.cpp), p = 1..8, N = 24//p."""
+    ref = {c["p"]: c for c in ANCHORS_VEC["cases"] if c["problem"] == f"bp{bp}"}
+    for p in range(1, 9):
+        txt = run([BIN / "bench_ceed", "-bp", bp, "-p", p, "-n", ref[p]["N"], "-reps", 2])
+        rows = [json.loads(l) for l in txt.splitlines() if l.startswith("{")]
+        ker = [r for r in rows if r["phase"] == "kernel"][0]
+        prob = [r for r in rows if r["phase"] == "problem"][0]
+        assert ker["dofs"] == ref[p]["dofs"]
+        assert abs(ker["norm_Ax"] - ref[p]["norm_Ax"]) <= 1e-12*ref[p]["norm_Ax"], (p, ker["norm_Ax"], ref[p]["norm_Ax"])
+        assert abs(prob["norm_B"] - ref[p]["norm_B"]) <= 1e-12*ref[p]["norm_B"]
+        assert prob["converged"] == 1
+        # rel tol 1e-12: the stopping decision can sit in rounding noise (DESIGN.md 4)
+        assert abs(prob["iterations"] - ref[p]["pcg_its"]) <= max(1, ref[p]["pcg_its"]//10), (p, prob["iterations"], ref[p]["pcg_its"])
+        assert abs(prob["norm_X"] - ref[p]["norm_X"]) <= 1e-8*ref[p]["norm_X"]
+
+
 # ---- every golden case through the C++ API (forms, integrators, solver) -------------------
 import sys
 sys.path.insert(0, str(ROOT / "tests"))
