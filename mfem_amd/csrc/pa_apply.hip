@@ -60,6 +60,25 @@ constexpr int minw_for(int KIND, int D, int PF = 0)
 #ifndef MFA_VGPR_CAP
 #define MFA_VGPR_CAP
 #endif
+// Where an element's Q x Q thread sheet tiles the 64-lane wavefront exactly (Q = 4: four elements
+// per wave, Q = 8: one), every LDS region of an element is written and read by ONE wave only:
+// the phases need no workgroup barrier, only program order within the wave (LDS instructions of a
+// wave execute in order) -- a compiler-level fence.  MFA_WAVE_SYNC=0 restores the barriers.
+#ifndef MFA_WAVE_SYNC
+#define MFA_WAVE_SYNC 1
+#endif
+template <bool WS>
+__device__ __forceinline__ void phase_sync()
+{
+   if (WS)
+   {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+   }
+   else { __syncthreads(); }
+}
+
 // RB (register-blocked x / transposed-y / transposed-x contractions): instead of one output per
 // thread and sweep (one LDS read per FMA), a thread owns one LDS row -- (dy,dz) for the x
 // contractions, (qx,dz) for the transposed y contraction -- reads it once and produces every
@@ -131,6 +150,8 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
       sB[i] = bg.b[i];
       if (KIND) { sG[i] = bg.g[i]; }
    }
+   constexpr bool WS = MFA_WAVE_SYNC && (64 % QQ == 0) && ABL == 0;
+   if (WS) { __syncthreads(); }           // the basis tables are shared by all waves: the only workgroup barrier
 
    static_assert(PF == 0 || (BLK && ABL == 0 && PF < Q), "streamed pa_data needs the blocked layout");
    double O[Q][NC];
@@ -295,7 +316,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
          }
          if (PERSIST) { load_gi(en); }       // next batch's gather indices: in flight from here
          if (VEC && comp + 1 < va.vd) { load_xv(e, comp + 1); }
-         __syncthreads();
+         phase_sync<WS>();
          if (ABL & 1)
          {
             double acc = sX[t2 % D];
@@ -377,7 +398,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
                if (KIND) { sGX[(dz*D + b)*QP + a] = v; }
             }
          }
-         __syncthreads();
+         phase_sync<WS>();
 
          // --- y contraction into register z-columns: thread (qx = a, qy = b)
          double r1[D], r2[D], r3[D];
@@ -419,7 +440,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
                   }
                }
             }
-            __syncthreads();
+            phase_sync<WS>();
 #pragma unroll
             for (int dz = 0; dz < D; dz++)
             {
@@ -508,7 +529,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
          }
          // all reads of sBX/sGX done; region A is reused as sT (RB == 2: every thread overwrites
          // exactly the sR entries it read itself -- no barrier)
-         if (RB != 2) { __syncthreads(); }
+         if (RB != 2) { phase_sync<WS>(); }
 #pragma unroll
          for (int dz = 0; dz < D; dz++)
          {
@@ -528,7 +549,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
             load_xv(en);
             if (PF == 0) { load_O(en, btn); }
          }
-         __syncthreads();
+         phase_sync<WS>();
 
          // --- transposed y contraction: thread (qx = a, dy = b); RB: thread t2 = (qx, dz), all dy
          asm volatile("s_mov_b32 %0, 0" : "=s"(zy));
@@ -588,7 +609,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
                if (KIND) { sV[DDQ + (dz*D + b)*QP + a] = v1; }
             }
          }
-         __syncthreads();
+         phase_sync<WS>();
 
          // --- transposed x contraction and store: thread (dx = a, dy = b); RB: thread t2 = row
          // (dz,dy), all dx -- D consecutive doubles of yE per thread
