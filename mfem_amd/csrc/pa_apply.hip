@@ -941,8 +941,15 @@ static int launch_apply(int64_t ne, const double *B, const double *G, const doub
       // the hot path has streamed and register-blocked variants
       const int pf = apply_pf(KIND, D, Q);
       const int rb = apply_rb(KIND, D, Q);
+      // compiled: every RB level with PF = 0, and the table's RB level with PF = 2, 3 (the environment
+      // overrides are tuning aids; the other combinations are refused)
 #define MFA_VARIANT(P, R) \
-      if (pf == P && rb == R) { return launch_apply<KIND, D, Q, GATHER, ACCUM, BLK, HOT ? P : 0, HOT ? R : 0, true>(ne, B, G, Dq, x, gmap, yE, s); }
+      if (pf == P && rb == R) \
+      { \
+         constexpr bool built = (P == 0) || (R == rb_table(KIND, D, Q)); \
+         MFA_REQUIRE(built, "pa_apply: the variant PF=%d RB=%d of (%d,%d) is not compiled in", P, R, D, Q); \
+         return launch_apply<KIND, D, Q, GATHER, ACCUM, BLK, (HOT && built) ? P : 0, (HOT && built) ? R : 0, true>(ne, B, G, Dq, x, gmap, yE, s); \
+      }
       MFA_VARIANT(0, 1) MFA_VARIANT(2, 0) MFA_VARIANT(2, 1) MFA_VARIANT(3, 0) MFA_VARIANT(3, 1)
       MFA_VARIANT(0, 2) MFA_VARIANT(2, 2) MFA_VARIANT(3, 2)
 #undef MFA_VARIANT

@@ -165,6 +165,44 @@ k_scatter(const int64_t ndofs, const int *__restrict__ offsets,
 // xE[(idx % nd) + nd*(c + vd*(idx / nd))] of its scalar dof's CSR row, in the same order.
 struct ScatVec { int vd, byvdim, nd; int64_t ndofs; };
 
+// JB entries of the row [j0, j0+m) for CB components starting at c0: loads batched, sums in order
+template <int MODE, int JB, int CB>
+__device__ __forceinline__ void scatter_vec_chunk(const ScatVec &sv, const int j0, const int m, const int c0,
+                                                  const int *__restrict__ indices, const double *__restrict__ xE,
+                                                  double (&v)[CB])
+{
+   int id[JB];
+   int64_t base[JB];
+   double t[JB][CB];
+#pragma unroll
+   for (int q = 0; q < JB; q++) { id[q] = indices[j0 + (q < m ? q : m - 1)]; }
+#pragma unroll
+   for (int q = 0; q < JB; q++)
+   {
+      const int64_t a = id[q] >= 0 ? id[q] : -1 - id[q];
+      base[q] = (a % sv.nd) + (int64_t)sv.nd*sv.vd*(a/sv.nd);
+   }
+#pragma unroll
+   for (int q = 0; q < JB; q++)
+   {
+#pragma unroll
+      for (int k = 0; k < CB; k++)
+      {
+         const int c = c0 + k < sv.vd ? c0 + k : sv.vd - 1;
+         t[q][k] = xE[base[q] + (int64_t)sv.nd*c];
+      }
+   }
+#pragma unroll
+   for (int q = 0; q < JB; q++)
+   {
+      if (q < m)
+      {
+#pragma unroll
+         for (int k = 0; k < CB; k++) { v[k] += (id[q] >= 0 || MODE == 2) ? t[q][k] : -t[q][k]; }
+      }
+   }
+}
+
 template <int MODE, bool DOT>
 __global__ void __launch_bounds__(256)
 k_scatter_vec(const ScatVec sv, const int *__restrict__ offsets,
@@ -173,43 +211,47 @@ k_scatter_vec(const ScatVec sv, const int *__restrict__ offsets,
               const double *__restrict__ xin, const double *__restrict__ w,
               double *__restrict__ partials, const int *__restrict__ skip)
 {
+   // One thread per SCALAR dof: its CSR row (offsets, indices, the / and % by nd) is read once for
+   // all components, three components at a time (vdim = 3 is the case that matters); rows of up to
+   // four entries (faces, interiors: most rows at p >= 3) take one batch of loads, longer ones
+   // (edges, vertices: most rows at p <= 2) batches of eight.
+   constexpr int CB = 3;
    __shared__ double s4[4];
    if (skip && *skip) { return; }
-   const int64_t n = sv.ndofs*sv.vd;
+   const int vd = sv.vd;
    double prod = 0.0;
-   for (int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x; i < n; i += (int64_t)gridDim.x*256)
+   for (int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x; i < sv.ndofs; i += (int64_t)gridDim.x*256)
    {
-      const int64_t dof = sv.byvdim ? i/sv.vd : i % sv.ndofs;
-      const int c = (int)(sv.byvdim ? i % sv.vd : i/sv.ndofs);
-      const int o0 = offsets[dof], o1 = offsets[dof + 1];
-      double v = 0.0;
-      for (int j0 = o0; j0 < o1; j0 += 8)
+      const int o0 = offsets[i], o1 = offsets[i + 1];
+      for (int c0 = 0; c0 < vd; c0 += CB)
       {
-         const int m = o1 - j0 < 8 ? o1 - j0 : 8;
-         int id[8];
-         double t[8];
+         double v[CB];
 #pragma unroll
-         for (int k = 0; k < 8; k++) { id[k] = indices[j0 + (k < m ? k : m - 1)]; }
-#pragma unroll
-         for (int k = 0; k < 8; k++)
+         for (int k = 0; k < CB; k++) { v[k] = 0.0; }
+         if (o1 - o0 <= 4) { if (o1 > o0) { scatter_vec_chunk<MODE, 4, CB>(sv, o0, o1 - o0, c0, indices, xE, v); } }
+         else
          {
-            const int64_t a = id[k] >= 0 ? id[k] : -1 - id[k];
-            t[k] = xE[(a % sv.nd) + (int64_t)sv.nd*(c + sv.vd*(a/sv.nd))];
+            for (int j0 = o0; j0 < o1; j0 += 8) { scatter_vec_chunk<MODE, 8, CB>(sv, j0, o1 - j0 < 8 ? o1 - j0 : 8, c0, indices, xE, v); }
          }
 #pragma unroll
-         for (int k = 0; k < 8; k++)
+         for (int k = 0; k < CB; k++)
          {
-            if (k < m) { v += (id[k] >= 0 || MODE == 2) ? t[k] : -t[k]; }
+            const int c = c0 + k;
+            if (c < vd)
+            {
+               const int64_t r = sv.byvdim ? i*vd + c : i + c*sv.ndofs;
+               double val = v[k];
+               if (marker)
+               {
+                  const unsigned char mk = marker[r];
+                  if (mk) { val = (mk == 1) ? xin[r] : 0.0; }
+               }
+               if (MODE == 1) { val += y[r]; }
+               y[r] = val;
+               if (DOT) { prod += w[r]*val; }
+            }
          }
       }
-      if (marker)
-      {
-         const unsigned char mk = marker[i];
-         if (mk) { v = (mk == 1) ? xin[i] : 0.0; }
-      }
-      if (MODE == 1) { v += y[i]; }
-      y[i] = v;
-      if (DOT) { prod += w[i]*v; }
    }
    if (DOT)
    {
@@ -326,7 +368,7 @@ extern "C" int mfem_amd_restrict_scatter_vdim(int64_t ndofs, int nd, int vdim, i
    MFA_REQUIRE(!(add && absv), "restrict_scatter_vdim: add and abs cannot be combined");
    MFA_REQUIRE(ndofs*vdim < ((int64_t)1 << 39), "restrict_scatter_vdim: too many vdofs");
    const ScatVec sv = {vdim, byvdim ? 1 : 0, nd, ndofs};
-   const unsigned nb = grid_for(ndofs*vdim);
+   const unsigned nb = grid_for(ndofs);
    hipStream_t s = as_stream(stream);
    if (absv) { k_scatter_vec<2, false><<<dim3(nb), dim3(256), 0, s>>>(sv, offsets, indices, xE, y, nullptr, nullptr, nullptr, nullptr, nullptr); }
    else if (add) { k_scatter_vec<1, false><<<dim3(nb), dim3(256), 0, s>>>(sv, offsets, indices, xE, y, nullptr, nullptr, nullptr, nullptr, nullptr); }
