@@ -64,6 +64,16 @@ constexpr int minw_for(int KIND, int D, int PF = 0)
 // per wave, Q = 8: one), every LDS region of an element is written and read by ONE wave only:
 // the phases need no workgroup barrier, only program order within the wave (LDS instructions of a
 // wave execute in order) -- a compiler-level fence.  MFA_WAVE_SYNC=0 restores the barriers.
+// tuning switch: basis factors of the row-per-thread phases from LDS (uniform-address reads)
+// instead of scalar loads from the kernel-argument segment
+#ifndef MFA_RB_LDS_BASIS
+#define MFA_RB_LDS_BASIS 0
+#endif
+#if MFA_RB_LDS_BASIS
+#define RBB(lo, UP, idx, off) s##UP[(idx) + vz]
+#else
+#define RBB(lo, UP, idx, off) bg.lo[(idx) + (off)]
+#endif
 #ifndef MFA_WAVE_SYNC
 #define MFA_WAVE_SYNC 1
 #endif
@@ -370,8 +380,8 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
 #pragma unroll
                   for (int dx = 0; dx < D; dx++)
                   {
-                     u += bg.b[qx*D + dx + zx]*sx[dx];
-                     if (KIND) { v += bg.g[qx*D + dx + zx]*sx[dx]; }
+                     u += RBB(b, B, qx*D + dx, zx)*sx[dx];
+                     if (KIND) { v += RBB(g, G, qx*D + dx, zx)*sx[dx]; }
                   }
                   sBX[t2*QP + qx] = u;
                   if (KIND) { sGX[t2*QP + qx] = v; }
@@ -570,11 +580,11 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
 #pragma unroll
                   for (int dy = 0; dy < D; dy++)
                   {
-                     v23[dy] += bg.b[qy*D + dy + zy]*T0;
+                     v23[dy] += RBB(b, B, qy*D + dy, zy)*T0;
                      if (KIND)
                      {
-                        v23[dy] += bg.g[qy*D + dy + zy]*T1;
-                        v1[dy] += bg.b[qy*D + dy + zy]*T2;
+                        v23[dy] += RBB(g, G, qy*D + dy, zy)*T1;
+                        v1[dy] += RBB(b, B, qy*D + dy, zy)*T2;
                      }
                   }
                }
@@ -629,8 +639,8 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
 #pragma unroll
                   for (int qx = 0; qx < Q; qx++)
                   {
-                     y += bg.b[qx*D + dx + zt]*V23[qx];
-                     if (KIND) { y += bg.g[qx*D + dx + zt]*V1[qx]; }
+                     y += RBB(b, B, qx*D + dx, zt)*V23[qx];
+                     if (KIND) { y += RBB(g, G, qx*D + dx, zt)*V1[qx]; }
                   }
                   yv[dx] = y;
                }
