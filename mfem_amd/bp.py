@@ -20,19 +20,27 @@ def _p(t):
 
 class BakeoffProblem:
     def __init__(self, problem, p, n, device, part=None, exchange=None, layout=1):
+        """`part`: None (serial Cartesian box of n elements), a BoxPartition, or a GeneralPartition of any hex
+        mesh's tables (then n is ignored)."""
         self.dev = torch.device(device)
         self.part, self.ex, self.layout = part, exchange, layout
         self.prob = part.prob if part is not None else CartesianProblem(p, n[0], n[1], n[2])
         pr = self.prob
         self.kind, self.D, self.Q, self.B, self.G, Bn, Gn, W = bakeoff_tables(problem, p)
         kind, D, Q = self.kind, self.D, self.Q
+        # nodal space of the mesh: trilinear for the synthetic boxes, order Dn-1 for mesh files
+        self.Dn = getattr(pr, "Dn", 2)
+        if self.Dn != 2:
+            from .tables import gauss_legendre, gauss_lobatto, lagrange_tables
+            qx, _ = gauss_lobatto(Q) if problem == "bp5" else gauss_legendre(Q)
+            Bn, Gn = lagrange_tables(gauss_lobatto(self.Dn)[0], qx)
         self.ne, self.ndofs = pr.ne, pr.ndofs
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
         self.stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
         self.gm, self.off, self.ind = t(pr.gather_map), t(pr.offsets), t(pr.indices)
         nodesE, Wd, one = t(pr.nodes_E), t(W), torch.ones(1, dtype=torch.float64, device=self.dev)
         self.pa = torch.zeros(capi.lib.mfem_amd_pa_data_size(kind, layout, Q, self.ne), dtype=torch.float64, device=self.dev)
-        capi.call("mfem_amd_pa_setup_from_nodes_3d", kind, 2, Q, 1, self.ne, Bn, Gn, _p(Wd), _p(nodesE), _p(one), 1,
+        capi.call("mfem_amd_pa_setup_from_nodes_3d", kind, self.Dn, Q, 1, self.ne, Bn, Gn, _p(Wd), _p(nodesE), _p(one), 1,
                   layout, _p(self.pa), None, self.stream)
         self.yE = torch.empty(self.ne*D**3, dtype=torch.float64, device=self.dev)
         # essential dofs: all six faces of the global box (bench_ceed.cpp:99-100)
@@ -105,12 +113,12 @@ class BakeoffProblem:
         Qm = self.Q
         qx, qw = (gauss_lobatto(Qm) if Qm == self.D else gauss_legendre(Qm))
         Bm, Gm = self.B, self.G
-        Bn, Gn = lagrange_tables(np.array([0.0, 1.0]), qx)
+        Bn, Gn = lagrange_tables(gauss_lobatto(self.Dn)[0], qx)
         W = np.ascontiguousarray((qw[None, None, :]*qw[None, :, None]*qw[:, None, None]).reshape(-1))
         pam = torch.zeros(capi.lib.mfem_amd_pa_data_size(0, 0, Qm, self.ne), dtype=torch.float64, device=self.dev)
         one = torch.ones(1, dtype=torch.float64, device=self.dev)
         Wd, nodesE = t(W), t(self.prob.nodes_E)      # keep the device tensors alive across the launch
-        capi.call("mfem_amd_pa_setup_from_nodes_3d", 0, 2, Qm, 1, self.ne, Bn, Gn, _p(Wd), _p(nodesE), _p(one),
+        capi.call("mfem_amd_pa_setup_from_nodes_3d", 0, self.Dn, Qm, 1, self.ne, Bn, Gn, _p(Wd), _p(nodesE), _p(one),
                   1, 0, _p(pam), None, self.stream)
         ones = torch.ones(self.ndofs, dtype=torch.float64, device=self.dev)
         b = torch.empty_like(ones)

@@ -49,6 +49,30 @@ def process_grid(world):
     return best[1]
 
 
+def _finish_shared_tables(part, ndofs):
+    """From part.upper / part.lower (lists of (neighbour rank, local dof ids), the ids in an order
+    both sides agree on): the flat pack/unpack index arrays, the CSR of the deterministic accumulate
+    (pfespace.cpp:5475-5494: unq_ltdof / unq_shr_i / unq_shr_j), the ghost mask and the owned count."""
+    part.upper.sort(key=lambda t: t[0])
+    part.lower.sort(key=lambda t: t[0])
+    cat = lambda lst: (np.concatenate([a for _, a in lst]) if lst else np.zeros(0, np.int32)).astype(np.int32)
+    part.shr_ltdof = cat(part.upper)          # owned dofs sent to sharers (repeats allowed)
+    part.ext_ldof = cat(part.lower)           # ghost dofs (each appears exactly once)
+    part.shr_sizes = [len(a) for _, a in part.upper]
+    part.ext_sizes = [len(a) for _, a in part.lower]
+    assert len(np.unique(part.ext_ldof)) == len(part.ext_ldof)
+    # CSR for the deterministic accumulate: unique owned-shared dof -> positions in shr_buf
+    order = np.argsort(part.shr_ltdof, kind="stable")
+    uniq, counts = np.unique(part.shr_ltdof, return_counts=True)
+    part.unq_ltdof = uniq.astype(np.int32)
+    part.unq_shr_i = np.zeros(len(uniq) + 1, np.int32)
+    np.cumsum(counts, out=part.unq_shr_i[1:])
+    part.unq_shr_j = order.astype(np.int32)   # ascending buffer position = ascending neighbour rank
+    part.ghost = np.zeros(ndofs, bool)
+    part.ghost[part.ext_ldof] = True
+    part.n_owned = int(ndofs - part.ghost.sum())
+
+
 class BoxPartition:
     """Local problem and shared-dof tables of rank `rank` in a (PX,PY,PZ) box grid with
     n = (nx,ny,nz) elements per rank and H1 order p."""
@@ -93,24 +117,7 @@ class BoxPartition:
         for off in itertools.product((0, -1), repeat=3):
             if any(off) and all(has_lo[d] for d in range(3) if off[d]):
                 self.lower.append((nbr_rank(off), index_set(off)))
-        self.upper.sort(key=lambda t: t[0])
-        self.lower.sort(key=lambda t: t[0])
-        cat = lambda lst: (np.concatenate([a for _, a in lst]) if lst else np.zeros(0, np.int32)).astype(np.int32)
-        self.shr_ltdof = cat(self.upper)          # owned dofs sent to sharers (repeats allowed)
-        self.ext_ldof = cat(self.lower)           # ghost dofs (each appears exactly once)
-        self.shr_sizes = [len(a) for _, a in self.upper]
-        self.ext_sizes = [len(a) for _, a in self.lower]
-        assert len(np.unique(self.ext_ldof)) == len(self.ext_ldof)
-        # CSR for the deterministic accumulate: unique owned-shared dof -> positions in shr_buf
-        order = np.argsort(self.shr_ltdof, kind="stable")
-        uniq, counts = np.unique(self.shr_ltdof, return_counts=True)
-        self.unq_ltdof = uniq.astype(np.int32)
-        self.unq_shr_i = np.zeros(len(uniq) + 1, np.int32)
-        np.cumsum(counts, out=self.unq_shr_i[1:])
-        self.unq_shr_j = order.astype(np.int32)   # ascending buffer position = ascending neighbour rank
-        self.ghost = np.zeros(self.prob.ndofs, bool)
-        self.ghost[self.ext_ldof] = True
-        self.n_owned = int(self.prob.ndofs - self.ghost.sum())
+        _finish_shared_tables(self, self.prob.ndofs)
 
     def local_to_global(self):
         """global lexicographic dof id of every local L-dof (tests)."""
@@ -124,6 +131,103 @@ class BoxPartition:
     def essential_marker(self):
         """1 = essential & owned, 2 = essential ghost copy, 0 otherwise; plus the dof list."""
         ess = self.prob.boundary_dofs()
+        m = np.zeros(self.prob.ndofs, np.uint8)
+        m[ess] = 1
+        m[ess[self.ghost[ess]]] = 2
+        return m, ess
+
+
+class MeshTables:
+    """Global (serial) tables of an H1 space on a hex mesh, as every rank holds them before the
+    partition (the reference builds ParMesh from the serial Mesh on every rank, mesh/pmesh.cpp:106-):
+    lexicographic element->dof map, E-nodes of the mesh's nodal space, essential dofs."""
+
+    def __init__(self, D1D, ndofs, gather_map, nodes_E, Dn, ess):
+        self.D1D, self.ndofs, self.Dn = int(D1D), int(ndofs), int(Dn)
+        nd = self.D1D**3
+        self.gather_map = np.ascontiguousarray(gather_map, np.int32).reshape(-1, nd)
+        self.ne = self.gather_map.shape[0]
+        self.nodes_E = np.ascontiguousarray(nodes_E, np.float64).reshape(self.ne, 3*self.Dn**3)
+        self.ess = np.ascontiguousarray(ess, np.int32)
+
+    @classmethod
+    def from_cartesian(cls, prob):
+        return cls(prob.p + 1, prob.ndofs, prob.gather_map, prob.nodes_E, 2, prob.boundary_dofs())
+
+    @classmethod
+    def from_case(cls, c):
+        """tests/golden case dict, or the files written by examples/bin/dump_tables (same keys)."""
+        return cls(c["D1D"], c["ndofs"], c["gather_map"], c["nodes_E"], c["nodes_D1D"], c["ess_tdof"])
+
+
+def chunk_partition(ne, world):
+    """Element partition without METIS: contiguous chunks of the element order (MFEM's Cartesian
+    meshes are Hilbert-ordered, so chunks are compact).  partition[e] = rank."""
+    return (np.arange(ne, dtype=np.int64)*world//ne).astype(np.int32)
+
+
+class _LocalProblem:
+    pass
+
+
+class GeneralPartition:
+    """Rank `rank`'s share of an arbitrary element partition of an unstructured hex mesh
+    (SURVEY 8f-3): local elements, local dof numbering, and the shared-dof tables the exchange
+    needs.  Restates what ParFiniteElementSpace derives from the group topology
+    (fem/pfespace.cpp:1804-1851, general/communication.cpp:97-267), from the serial tables:
+      * a dof is shared by the ranks whose elements touch it (its group);
+      * its owner (group master) is the lowest rank of the group (communication.cpp:120-124);
+      * exchanges run owner <-> sharers, lists ordered by global dof id on both sides.
+    Local dofs are numbered by ascending global id; local elements keep their global order.
+    The partition itself (METIS in the reference, mesh/mesh.cpp:9106-9195) is an input here:
+    any vector works, `chunk_partition` is the METIS-free default -- parity of the partition is
+    unpinned, the partitioned solve is pinned to the serial one (tests/test_parallel_gloo.py)."""
+
+    def __init__(self, tables, partition, rank):
+        partition = np.asarray(partition)
+        assert partition.shape == (tables.ne,)
+        self.tables, self.rank = tables, rank
+        nd = tables.D1D**3
+        mine = np.flatnonzero(partition == rank)
+        self.elements = mine
+        gm = tables.gather_map[mine]                                  # (ne_loc, nd) global ids
+        l2g = np.unique(gm)                                           # ascending global id
+        self.l2g = l2g
+        pr = _LocalProblem()
+        pr.ne, pr.ndofs, pr.Dn = len(mine), len(l2g), tables.Dn
+        pr.gather_map = np.searchsorted(l2g, gm).astype(np.int32).reshape(-1)
+        order = np.argsort(pr.gather_map, kind="stable")              # element-major within a dof (restriction.cpp:86-99)
+        pr.indices = order.astype(np.int32)
+        pr.offsets = np.zeros(pr.ndofs + 1, np.int32)
+        np.cumsum(np.bincount(pr.gather_map, minlength=pr.ndofs), out=pr.offsets[1:])
+        pr.nodes_E = np.ascontiguousarray(tables.nodes_E[mine].reshape(-1))
+        self.prob = pr
+        # groups: (dof, rank) pairs over the whole mesh
+        pairs = np.unique(np.stack([tables.gather_map.reshape(-1).astype(np.int64),
+                                    np.repeat(partition.astype(np.int64), nd)], axis=1), axis=0)
+        dofs, ranks = pairs[:, 0], pairs[:, 1]
+        first = np.r_[True, dofs[1:] != dofs[:-1]]
+        owner_of = np.full(tables.ndofs, -1, np.int64)
+        owner_of[dofs[first]] = ranks[first]                          # pairs are sorted: first = lowest rank
+        self.owner = owner_of[l2g]
+        # dofs I own that other ranks touch: those ranks get my value (P) and send me their sums (P^T)
+        mine_shared = (owner_of[dofs] == rank) & (ranks != rank)
+        up, lo = {}, {}
+        for g, r in zip(dofs[mine_shared], ranks[mine_shared]):
+            up.setdefault(int(r), []).append(g)
+        for g in l2g[self.owner != rank]:
+            lo.setdefault(int(owner_of[g]), []).append(g)
+        loc = lambda gl: np.searchsorted(l2g, np.sort(np.asarray(gl, np.int64))).astype(np.int32)
+        self.upper = [(r, loc(g)) for r, g in up.items()]
+        self.lower = [(r, loc(g)) for r, g in lo.items()]
+        _finish_shared_tables(self, pr.ndofs)
+
+    def local_to_global(self):
+        return self.l2g, None
+
+    def essential_marker(self):
+        """1 = essential & owned, 2 = essential ghost copy, 0 otherwise; plus the local dof list."""
+        ess = np.flatnonzero(np.isin(self.l2g, self.tables.ess)).astype(np.int32)
         m = np.zeros(self.prob.ndofs, np.uint8)
         m[ess] = 1
         m[ess[self.ghost[ess]]] = 2

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _worker(rank, world, port, problem, p, n, out):
+def _worker(rank, world, port, problem, p, n, out, mode="box"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, str(ROOT))
     import torch
@@ -22,17 +22,31 @@ def _worker(rank, world, port, problem, p, n, out):
     try:
         from mfem_amd import capi
         from mfem_amd.bp import BakeoffProblem
-        from mfem_amd.parallel import BoxPartition, Exchange, process_grid
+        from mfem_amd.parallel import BoxPartition, Exchange, GeneralPartition, MeshTables, process_grid
         capi.call("mfem_amd_init", 0)
         torch.cuda.set_device(0)
         pg = process_grid(world)
-        part = BoxPartition(p, (n, n, n), pg, rank)
+        if mode == "box":
+            part = BoxPartition(p, (n, n, n), pg, rank)
+        else:
+            # arbitrary element partition of a Cartesian mesh's tables, or of a curved mesh file's
+            # tables taken from the reference fixtures (order-3 nodes)
+            sys.path.insert(0, str(ROOT / "tests"))
+            from conftest import load_case
+            from mfem_amd.cartesian import CartesianProblem
+            tabs = (MeshTables.from_case(load_case("toroid-hex_diff_p3")) if mode == "toroid"
+                    else MeshTables.from_cartesian(CartesianProblem(p, 2*n, n, n + 1)))
+            pv = np.random.default_rng(5).integers(0, world, tabs.ne).astype(np.int32)
+            part = GeneralPartition(tabs, pv, rank)
         ex = Exchange(part, "cuda:0")
         bp = BakeoffProblem(problem, p, (n, n, n), "cuda:0", part=part, exchange=ex)
         b = bp.rhs_unit_source()
         X, res, hist = bp.pcg(b, 1e-10, max_iter=1000, check_every=4, want_hist=True)
         # serial solve of the global problem on the same GPU
-        sp = BakeoffProblem(problem, p, (pg[0]*n, pg[1]*n, pg[2]*n), "cuda:0")
+        if mode == "box":
+            sp = BakeoffProblem(problem, p, (pg[0]*n, pg[1]*n, pg[2]*n), "cuda:0")
+        else:
+            sp = BakeoffProblem(problem, p, None, "cuda:0", part=GeneralPartition(tabs, np.zeros(tabs.ne, np.int32), 0))
         Xs, rs, hs = sp.pcg(sp.rhs_unit_source(), 1e-10, max_iter=1000, check_every=4, want_hist=True)
         torch.cuda.synchronize()
         l2g, _ = part.local_to_global()
@@ -60,13 +74,14 @@ def _worker(rank, world, port, problem, p, n, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("problem,p,n", [("bp3", 3, 4), ("bp1", 2, 5)])
-def test_two_ranks_match_serial(problem, p, n):
+@pytest.mark.parametrize("problem,p,n,mode", [("bp3", 3, 4, "box"), ("bp1", 2, 5, "box"), ("bp3", 2, 3, "random"),
+                                              ("bp3", 3, 0, "toroid")])
+def test_two_ranks_match_serial(problem, p, n, mode):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    port = 29700 + (os.getpid() % 1000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, problem, p, n, out)) for r in range(2)]
+    port = 29700 + (os.getpid() % 1000) + 7*len(mode)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, problem, p, n, out, mode)) for r in range(2)]
     for pr in procs:
         pr.start()
     res = [out.get(timeout=110) for _ in range(2)]

@@ -19,20 +19,21 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 
-def _tables(p, Q):
+def _tables(p, Q, pn=1):
     import oracle_lib as orc
     x, w = orc.gauss_legendre(Q)
     B, G = orc.basis_1d(p, x)
-    Bn, Gn = orc.basis_1d(1, x)
+    Bn, Gn = orc.basis_1d(pn, x)
     return B, G, Bn, Gn, orc.tensor_weights(w)
 
 
 def _oracle_operator(prob, p, Q, kind, ess):
     import oracle_lib as orc
-    B, G, Bn, Gn, W = _tables(p, Q)
+    Dn = getattr(prob, "Dn", 2)
+    B, G, Bn, Gn, W = _tables(p, Q, Dn - 1)
     ne = prob.ne
     J = np.zeros(9*Q**3*ne)
-    orc.lib.orc_jacobians_3d(2, Q, ne, Bn, Gn, prob.nodes_E, J)
+    orc.lib.orc_jacobians_3d(Dn, Q, ne, Bn, Gn, prob.nodes_E, J)
     if kind:
         pa = np.zeros(6*Q**3*ne)
         orc.lib.orc_diffusion_setup_3d(Q, 1, ne, W, J, np.ones(1), 1, pa)
@@ -42,22 +43,39 @@ def _oracle_operator(prob, p, Q, kind, ess):
     return orc.Operator(kind, p + 1, Q, ne, prob.ndofs, B, G, pa, prob.gather_map, prob.offsets, prob.indices, ess)
 
 
-def _worker(rank, world, port, p, n, kind, out):
+def _worker(rank, world, port, p, n, kind, out, mode="box"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import oracle_lib as orc
         from mfem_amd.cartesian import CartesianProblem
-        from mfem_amd.parallel import BoxPartition, Exchange, process_grid
-        from conftest import splitmix
+        from mfem_amd.parallel import (BoxPartition, Exchange, GeneralPartition, MeshTables, chunk_partition,
+                                       process_grid)
+        from conftest import load_case, splitmix
         pg = process_grid(world)
-        part = BoxPartition(p, (n, n, n), pg, rank)
-        ex = Exchange(part, "cpu")
         Q = p + 2
+        if mode == "box":
+            part = BoxPartition(p, (n, n, n), pg, rank)
+            # ---- serial problem on the global box (every rank builds it; small)
+            gprob = CartesianProblem(p, pg[0]*n, pg[1]*n, pg[2]*n)
+            gess = gprob.boundary_dofs()
+        else:
+            # arbitrary element partitions of the serial tables: contiguous chunks, a random
+            # assignment, and a curved mesh file's tables from the reference fixtures
+            if mode == "toroid":
+                c = load_case("toroid-hex_diff_p2")
+                tabs = MeshTables.from_case(c)
+                Q = c["Q1D"]
+            else:
+                tabs = MeshTables.from_cartesian(CartesianProblem(p, 2*n, n, n + 1))
+            pv = (chunk_partition(tabs.ne, world) if mode != "random"
+                  else np.random.default_rng(3).integers(0, world, tabs.ne).astype(np.int32))
+            part = GeneralPartition(tabs, pv, rank)
+            gprob = GeneralPartition(tabs, np.zeros(tabs.ne, np.int32), 0).prob      # the serial problem
+            assert np.array_equal(gprob.gather_map, tabs.gather_map.reshape(-1))
+            gess = tabs.ess
+        ex = Exchange(part, "cpu")
         l2g, g1 = part.local_to_global()
-        # ---- serial problem on the global box (every rank builds it; small)
-        gprob = CartesianProblem(p, pg[0]*n, pg[1]*n, pg[2]*n)
-        gess = gprob.boundary_dofs()
         gop = _oracle_operator(gprob, p, Q, kind, gess)
         xg = splitmix(5, gprob.ndofs)
         # ---- ownership: every global dof owned exactly once
@@ -135,12 +153,14 @@ def _worker(rank, world, port, p, n, kind, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,p,n,kind", [(2, 2, 2, 1), (2, 3, 2, 0), (8, 2, 2, 1), (4, 1, 3, 1)])
-def test_partitioned_operator_and_pcg_match_serial(world, p, n, kind):
+@pytest.mark.parametrize("world,p,n,kind,mode", [(2, 2, 2, 1, "box"), (2, 3, 2, 0, "box"), (8, 2, 2, 1, "box"), (4, 1, 3, 1, "box"),
+                                                 (3, 2, 2, 1, "chunks"), (4, 2, 2, 1, "random"), (2, 3, 2, 0, "random"),
+                                                 (2, 2, 0, 1, "toroid"), (3, 2, 0, 1, "toroid")])
+def test_partitioned_operator_and_pcg_match_serial(world, p, n, kind, mode):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, p, n, kind, out)) for r in range(world)]
+    port = 29500 + (os.getpid() % 2000) + world + 16*len(mode)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, p, n, kind, out, mode)) for r in range(world)]
     for pr in procs:
         pr.start()
     res = [out.get(timeout=300) for _ in range(world)]
