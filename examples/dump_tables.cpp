@@ -94,6 +94,8 @@ int main(int argc, char **argv)
    dump("nodes.f64", nodes->HostRead(), nodes->Size());
    const ElementRestriction *NR = nodes->FESpace()->GetElementRestriction(ElementDofOrdering::LEXICOGRAPHIC);
    dump("nodes_gather_map.i32", NR->GatherMap().HostRead(), NR->GatherMap().Size());
+   const int nodes_byvdim = nodes->FESpace()->GetOrdering() == Ordering::byVDIM ? 1 : 0;
+   dump("nodes_byvdim.i32", &nodes_byvdim, 1);
    const DofToQuad &nm = nodes->FESpace()->GetTypicalFE()->GetDofToQuad(*ir, DofToQuad::TENSOR);
    dump("nodes_B.f64", nm.B.HostRead(), nm.B.Size()); dump("nodes_G.f64", nm.G.HostRead(), nm.G.Size());
    printf("NE=%d ndofs=%d nedges=%d nfaces=%d D1D=%d Q1D=%d ness=%d\n", NE, fes.GetNDofs(), mesh->GetNEdges(), mesh->GetNFaces(),

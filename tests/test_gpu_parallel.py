@@ -89,3 +89,41 @@ def test_two_ranks_match_serial(problem, p, n, mode):
         pr.join(30)
     bad = [m for _, m in res if m != "ok"]
     assert not bad, bad[0]
+
+
+def test_ex1p_driver_two_ranks_equals_one_rank_and_serial_ex1():
+    """examples/ex1p.py (one process per GPU; here 2 ranks over gloo on one GPU) on a curved mesh file: the same
+    unknown count and (B r, r) history as one rank and as the serial C++ ex1 on the same refined mesh."""
+    import re
+    import subprocess
+    mesh = str(ROOT / "tests" / "golden" / "meshes" / "toroid-hex.mesh")
+    env = dict(os.environ, MFEM_AMD_DIST_BACKEND="gloo")
+
+    def parse(txt):
+        n = int(re.search(r"Number of finite element unknowns: (\d+)", txt).group(1))
+        hist = [float(m) for m in re.findall(r"Iteration :\s+\d+\s+\(B r, r\) = (\S+)", txt)]
+        return n, hist
+
+    outs = {}
+    for nr in (1, 2):
+        port = 29850 + (os.getpid() % 500) + nr
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nr}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), str(ROOT / "examples" / "ex1p.py"), "-m", mesh, "-o", "2", "-r", "2"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=str(ROOT))
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        outs[nr] = parse(r.stdout)
+        assert f"ranks = {nr}" in r.stdout
+    r = subprocess.run([str(ROOT / "examples" / "bin" / "ex1"), "-m", mesh, "-o", "2", "-r", "2", "-pa", "-d", "hip", "-no-vis", "-no-save"],
+                       capture_output=True, text=True, timeout=280, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-1500:]
+    n_ser, h_ser = parse(r.stdout)
+    (n1, h1), (n2, h2) = outs[1], outs[2]
+    assert n1 == n2 == n_ser
+    assert abs(len(h1) - len(h2)) <= 1                 # rel tol 1e-12: the last decision sits in rounding
+    m = min(len(h1), len(h2), len(h_ser))              # ex1 stops earlier (PCG(...,1e-12) = rel tol 1e-6)
+    h1, h2, h_ser = np.array(h1[:m]), np.array(h2[:m]), np.array(h_ser[:m])
+    big = h_ser > 1e-10*h_ser[0]
+    # same recurrence, different dof numbering and dot-product order: the rounding differences grow along CG
+    # (2e-5 relative ten orders below the start); the first iterations agree to the 6 printed digits
+    assert np.all(np.abs(h1[big] - h_ser[big]) <= 1e-3*h_ser[big]) and np.all(np.abs(h2[big] - h_ser[big]) <= 1e-3*h_ser[big])
+    assert np.all(np.abs(h1[:6] - h_ser[:6]) <= 2e-6*h_ser[:6]) and np.all(np.abs(h2[:6] - h_ser[:6]) <= 2e-6*h_ser[:6])
