@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--elems", type=int, default=0, help="elements per direction per GPU (default: ~1e7 dofs per GPU)")
     ap.add_argument("--problem", default="bp3", choices=["bp1", "bp3", "bp5"])
     ap.add_argument("--cg-iters", type=int, default=50)
+    ap.add_argument("--no-orders", action="store_true", help="skip the p = 1..8 table (N=1 only; ~10 s)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args()
@@ -134,9 +135,11 @@ def main():
         el = float(tt.item())
     value = total_dofs*args.steps/el/1e9
 
-    # per-kernel durations on this rank (HIP events on the launch stream), same K
-    t_l2e = timed(lambda: bp.l2e(x), args.steps)/args.steps
-    t_e2l = timed(lambda: bp.e2l(y), args.steps)/args.steps
+    # per-kernel average launch durations on this rank (HIP events on the launch stream), K launches per
+    # block; the median of three blocks (box-to-box and clock noise is +-5 % on a 17 ms block)
+    med3 = lambda fn: sorted(timed(fn, args.steps) for _ in range(3))[1]/args.steps
+    t_l2e = med3(lambda: bp.l2e(x))
+    t_e2l = med3(lambda: bp.e2l(y))
     b_l2e, b_e2l = algorithmic_bytes(kind, D, Q, ne, ndofs)
     roof = {"bound": "hbm", "kernel": "k_pa_apply (fused L->E gather + element kernel)",
             "achieved": b_l2e/t_l2e/1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -171,6 +174,28 @@ def main():
         cg = {"iters": it, "dofs_iter_per_s": total_dofs*it/tcg, "ms_per_iter": tcg/it*1e3,
               "hbm_frac_per_gpu": cg_bytes/tcg/1e9/HBM_PEAK_GBS, "final_nom": res.final_nom, "initial_nom": res.initial_nom}
 
+    # the metric's "p = 1..8": the same step at every order, ~1e7 dofs each, 20 steps (N = 1 only).  The
+    # headline `value` stays the p = 4 workload above; this table rides along in the same JSON line.
+    by_order = None
+    if world == 1 and not args.no_orders:
+        by_order = []
+        del bp, x, y
+        torch.cuda.empty_cache()
+        for q in range(1, 9):
+            nq = max(1, round((1.0e7)**(1.0/3.0)/q))
+            bq = BakeoffProblem(args.problem, q, (nq, nq, nq), dev)
+            xq = torch.rand(bq.ndofs, dtype=torch.float64, generator=g).to(dev)
+            yq = torch.empty_like(xq)
+            for _ in range(3):
+                bq.mult(xq, yq)
+            tq = timed(lambda: bq.mult(xq, yq), 20)/20
+            tl = timed(lambda: bq.l2e(xq), 20)/20
+            b1, b2 = algorithmic_bytes(bq.kind, bq.D, bq.Q, bq.ne, bq.ndofs)
+            by_order.append({"p": q, "dofs": bq.ndofs, "GDOF/s": bq.ndofs/tq/1e9, "ms_per_step": tq*1e3,
+                             "apply_frac": (b1 + b2)/tq/1e9/HBM_PEAK_GBS, "l2e_ms": tl*1e3, "l2e_frac": b1/tl/1e9/HBM_PEAK_GBS})
+            del bq, xq, yq
+            torch.cuda.empty_cache()
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         from mfem_amd.tables import bakeoff_tables
@@ -185,7 +210,7 @@ def main():
                                       f"D1D={D} Q1D={Q}, Cartesian hex mesh {n}^3 per GPU",
                           "elements_per_gpu": ne, "local_dofs_per_gpu": ndofs, "global_dofs": total_dofs,
                           "process_grid": list(pg)},
-               "roofline": roof, "roofline_apply": roof_apply, "cg": cg, "cpu_baseline": cpu,
+               "roofline": roof, "roofline_apply": roof_apply, "cg": cg, "by_order": by_order, "cpu_baseline": cpu,
                "setup_s": setup_s}
         print(json.dumps(out))
     if world > 1:
