@@ -175,3 +175,39 @@ def test_constrained_vector_operator_and_pcg(name, byvdim):
         assert np.max(np.abs(part - fac[k]*Xs)) <= 1e-9*np.max(np.abs(Xs)), (name, k)
     # (B r, r) of the block system = (1 + 1/4 + 4) x the scalar one, up to the dot products' rounding
     assert abs(hist[0] - 5.25*hs[0]) <= 1e-12*hist[0]
+
+
+@pytest.mark.parametrize("vd", [1, 2, 4, 5])
+@pytest.mark.parametrize("byvdim", [0, 1])
+def test_other_component_counts_and_edge_cases(vd, byvdim):
+    """vdim = 1, 2, 4, 5 (the transpose-gather works three components at a time, the element kernel loops),
+    the generic fallback kernel, an empty mesh, and the argument checks."""
+    from gpu_helpers import DeviceOperator, dev, host, ptr, zeros
+    from mfem_amd import capi
+    capi.call("mfem_amd_init", 0)
+    for name in ("cart2_bp3_p2", "fichera-q3_massvar_p2"):           # (3,4) specialised; (3,7) -> fallback kernel
+        c = load_case(name)
+        kind, D, Q, NE, nd = int(c["kind"]), int(c["D1D"]), int(c["Q1D"]), int(c["NE"]), int(c["ndofs"])
+        op = DeviceOperator(c, layout=0)
+        rng = np.random.default_rng(vd)
+        comps = [rng.random(nd) for _ in range(vd)]
+        x, yE, y = dev(to_vec(comps, byvdim)), zeros(NE*D**3*vd), zeros(nd*vd)
+        capi.call("mfem_amd_pa_apply_L2E_vdim", kind, 0, D, Q, NE, vd, byvdim, nd, op.B, op.G, ptr(op.pa), 0,
+                  ptr(op.gm), None, ptr(x), ptr(yE), None)
+        capi.call("mfem_amd_restrict_scatter_vdim", nd, D**3, vd, byvdim, ptr(op.off), ptr(op.ind), ptr(yE), ptr(y), 0, 0, None)
+        for k, part in enumerate(split(host(y), nd, vd, byvdim)):
+            xk = dev(comps[k])
+            assert np.array_equal(part, host(op.apply_L2L(xk))), (name, vd, k)
+        # replicate: y[vdof(i,c)] = scale[c]*x[i]
+        sc = np.arange(1.0, vd + 1.0)
+        xs, yr = dev(comps[0]), zeros(nd*vd)
+        capi.call("mfem_amd_vec_replicate_vdim", nd, vd, byvdim, sc.ctypes.data_as(C.c_void_p), ptr(xs), ptr(yr), None)
+        for k, part in enumerate(split(host(yr), nd, vd, byvdim)):
+            assert np.array_equal(part, sc[k]*comps[0])
+    # empty mesh / empty space: no launch, no error
+    capi.call("mfem_amd_pa_apply_L2E_vdim", 1, 0, 3, 4, 0, vd, byvdim, 0, op.B, op.G, ptr(op.pa), 0, ptr(op.gm), None, ptr(x), ptr(yE), None)
+    capi.call("mfem_amd_restrict_scatter_vdim", 0, 27, vd, byvdim, ptr(op.off), ptr(op.ind), ptr(yE), ptr(y), 0, 0, None)
+    with pytest.raises(capi.MfemAmdError, match="vdim"):
+        capi.call("mfem_amd_pa_apply_L2E_vdim", kind, 0, D, Q, NE, 0, byvdim, nd, op.B, op.G, ptr(op.pa), 0, ptr(op.gm), None, ptr(x), ptr(yE), None)
+    with pytest.raises(capi.MfemAmdError, match="add and abs"):
+        capi.call("mfem_amd_restrict_scatter_vdim", nd, D**3, vd, byvdim, ptr(op.off), ptr(op.ind), ptr(yE), ptr(y), 1, 1, None)
