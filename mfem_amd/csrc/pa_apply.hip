@@ -51,7 +51,9 @@ constexpr int minw_for(int KIND, int D, int PF = 0)
 // vmcnt retires in order, so the (small, needed-first) x gather is issued before the
 // pa_data stream.
 // ABL (tuning builds only, tools/ablate.hip): 0 = the kernel; 1 = memory traffic only (loads +
-// stores, no contractions); 2 = contractions only (pa_data not read).
+// stores, no contractions); 2 = contractions only (pa_data not read).  With 2, further bits switch
+// parts of the contractions off (timing only, results meaningless): 512 = basis factors are
+// literals (no scalar loads), 1024 = no z loop, 2048 = no y contraction, 4096 = no transposed y.
 // PF > 0 (blocked layout only): pa_data is streamed through the z loop instead of being held
 // whole in registers -- PF z-slices (6 doubles per thread each) are in flight at any time;
 // slice qz+PF is requested when slice qz is consumed, and in the persistent schedule the ring
@@ -72,8 +74,9 @@ constexpr int minw_for(int KIND, int D, int PF = 0)
 #if MFA_RB_LDS_BASIS
 #define RBB(lo, UP, idx, off) s##UP[(idx) + vz]
 #else
-#define RBB(lo, UP, idx, off) bg.lo[(idx) + (off)]
+#define RBB(lo, UP, idx, off) ((ABL & 512) ? (0.25 + 0.0625*(idx)) : bg.lo[(idx) + (off)])
 #endif
+#define ZBB(lo, idx, off) ((ABL & 512) ? (0.25 + 0.0625*(idx)) : bg.lo[(idx) + (off)])
 #ifndef MFA_WAVE_SYNC
 #define MFA_WAVE_SYNC 1
 #endif
@@ -160,7 +163,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
       sB[i] = bg.b[i];
       if (KIND) { sG[i] = bg.g[i]; }
    }
-   constexpr bool WS = MFA_WAVE_SYNC && (64 % QQ == 0) && ABL == 0;
+   constexpr bool WS = MFA_WAVE_SYNC && (64 % QQ == 0) && (ABL == 0 || (ABL & 2));
    if (WS) { __syncthreads(); }           // the basis tables are shared by all waves: the only workgroup barrier
 
    static_assert(PF == 0 || (BLK && ABL == 0 && PF < Q), "streamed pa_data needs the blocked layout");
@@ -459,6 +462,11 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
                r1[dz] = KIND ? sT[tix(2*D + dz, b, a)] : 0.0;
             }
          }
+         else if (ABL & 2048)
+         {
+#pragma unroll
+            for (int dz = 0; dz < D; dz++) { r1[dz] = sBX[(dz*D + (b % D))*QP + a]; r2[dz] = r1[dz] + 1.0; r3[dz] = r1[dz] + 2.0; }
+         }
          else
          {
             double Bb[D], Gb[D];
@@ -493,6 +501,12 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
          double t1[D], t2r[D], t3[D];
 #pragma unroll
          for (int dz = 0; dz < D; dz++) { t1[dz] = 0.0; t2r[dz] = 0.0; t3[dz] = 0.0; }
+         if (ABL & 1024)
+         {
+#pragma unroll
+            for (int dz = 0; dz < D; dz++) { t1[dz] = r1[dz] + O[dz % Q][0]; t2r[dz] = r2[dz]; t3[dz] = r3[dz]; }
+         }
+         else
 #pragma unroll
          for (int qz = 0; qz < Q; qz++)
          {
@@ -508,7 +522,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
 #pragma unroll
                for (int dz = 0; dz < D; dz++)
                {
-                  const double bz = bg.b[qz*D + dz + zofs], gz = bg.g[qz*D + dz + zofs];
+                  const double bz = ZBB(b, qz*D + dz, zofs), gz = ZBB(g, qz*D + dz, zofs);
                   gX += bz*r1[dz];
                   gY += bz*r2[dz];
                   gZ += gz*r3[dz];
@@ -521,7 +535,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
 #pragma unroll
                for (int dz = 0; dz < D; dz++)
                {
-                  const double bz = bg.b[qz*D + dz + zofs], gz = bg.g[qz*D + dz + zofs];
+                  const double bz = ZBB(b, qz*D + dz, zofs), gz = ZBB(g, qz*D + dz, zofs);
                   t1[dz] += bz*fX;
                   t2r[dz] += bz*fY;
                   t3[dz] += gz*fZ;
@@ -531,10 +545,10 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
             {
                double u = 0.0;
 #pragma unroll
-               for (int dz = 0; dz < D; dz++) { u += bg.b[qz*D + dz + zofs]*r3[dz]; }
+               for (int dz = 0; dz < D; dz++) { u += ZBB(b, qz*D + dz, zofs)*r3[dz]; }
                u *= O[qz][0];
 #pragma unroll
-               for (int dz = 0; dz < D; dz++) { t3[dz] += bg.b[qz*D + dz + zofs]*u; }
+               for (int dz = 0; dz < D; dz++) { t3[dz] += ZBB(b, qz*D + dz, zofs)*u; }
             }
          }
          // all reads of sBX/sGX done; region A is reused as sT (RB == 2: every thread overwrites
@@ -563,7 +577,20 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
 
          // --- transposed y contraction: thread (qx = a, dy = b); RB: thread t2 = (qx, dz), all dy
          asm volatile("s_mov_b32 %0, 0" : "=s"(zy));
-         if (RB)
+         if (RB && (ABL & 4096))
+         {
+            if (t2 < Q*D)
+            {
+               const int qx = t2 % Q, dz = t2 / Q;
+#pragma unroll
+               for (int dy = 0; dy < D; dy++)
+               {
+                  sV[(dz*D + dy)*QP + qx] = sT[tix(dz, dy, qx)];
+                  if (KIND) { sV[DDQ + (dz*D + dy)*QP + qx] = sT[tix(D + dz, dy, qx)]; }
+               }
+            }
+         }
+         else if (RB)
          {
             if (t2 < Q*D)
             {
