@@ -1079,7 +1079,11 @@ static int launch_apply_vec(int64_t ne, const double *B, const double *G, const 
                             const double *x, const int *gmap, double *yE, VecArgs va, hipStream_t s)
 {
    constexpr int NBZ = nbz_for(Q);
+#ifdef MFA_VEC_RB
+   constexpr int RBV = Q > 3 ? MFA_VEC_RB : 0;
+#else
    constexpr int RBV = Q > 3 ? rb_table(KIND, D, Q) : 0;
+#endif
    auto kern = k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM, BLK, 0, false, 0, RBV, true>;
    BasisT<D*Q> bg;
    fill_basis(bg, D, Q, B, G);
