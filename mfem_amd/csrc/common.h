@@ -24,12 +24,30 @@ struct BasisT
    double g[N];
 };
 
-// Elements per workgroup of the specialised apply kernels (Q*Q*NBZ ~ 200..256 threads).
+// Elements per workgroup of the specialised apply kernels (Q*Q*NBZ ~ 200..256 threads; Q = 8: two
+// one-wave elements -- measured 6 % faster than four for the collocated and vector kernels, equal
+// otherwise; halving the other sizes was equal or slower, profiles/r1/sweep_nbz_half.txt).
 // Also the blocking factor of the HBM-friendly pa_data layout below.
+// (MFA_NBZ<Q>: tuning overrides -- every source file must see the same values.)
+#ifndef MFA_NBZ4
+#define MFA_NBZ4 16
+#endif
+#ifndef MFA_NBZ5
+#define MFA_NBZ5 10
+#endif
+#ifndef MFA_NBZ6
+#define MFA_NBZ6 7
+#endif
+#ifndef MFA_NBZ7
+#define MFA_NBZ7 5
+#endif
+#ifndef MFA_NBZ8
+#define MFA_NBZ8 2
+#endif
 __host__ __device__ constexpr int nbz_for(int Q)
 {
-   return Q <= 2 ? 32 : Q == 3 ? 16 : Q == 4 ? 16 : Q == 5 ? 10 : Q == 6 ? 7 :
-          Q == 7 ? 5 : Q == 8 ? 4 : Q == 9 ? 3 : 2;
+   return Q <= 2 ? 32 : Q == 3 ? 16 : Q == 4 ? MFA_NBZ4 : Q == 5 ? MFA_NBZ5 : Q == 6 ? MFA_NBZ6 :
+          Q == 7 ? MFA_NBZ7 : Q == 8 ? MFA_NBZ8 : Q == 9 ? 3 : 2;
 }
 
 // Blocked pa_data layout (layout 1).  The reference stores D as (q, component, element)
