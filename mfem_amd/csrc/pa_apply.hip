@@ -66,16 +66,8 @@ constexpr int minw_for(int KIND, int D, int PF = 0)
 // per wave, Q = 8: one), every LDS region of an element is written and read by ONE wave only:
 // the phases need no workgroup barrier, only program order within the wave (LDS instructions of a
 // wave execute in order) -- a compiler-level fence.  MFA_WAVE_SYNC=0 restores the barriers.
-// tuning switch: basis factors of the row-per-thread phases from LDS (uniform-address reads)
-// instead of scalar loads from the kernel-argument segment
-#ifndef MFA_RB_LDS_BASIS
-#define MFA_RB_LDS_BASIS 0
-#endif
-#if MFA_RB_LDS_BASIS
-#define RBB(lo, UP, idx, off) s##UP[(idx) + vz]
-#else
+// basis factors as scalar operands (ABL & 512, tuning builds: literals instead)
 #define RBB(lo, UP, idx, off) ((ABL & 512) ? (0.25 + 0.0625*(idx)) : bg.lo[(idx) + (off)])
-#endif
 #define ZBB(lo, idx, off) ((ABL & 512) ? (0.25 + 0.0625*(idx)) : bg.lo[(idx) + (off)])
 #ifndef MFA_WAVE_SYNC
 #define MFA_WAVE_SYNC 1
@@ -228,7 +220,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
          else { xv[k] = xe[i < D3 ? i : D3 - 1]; }
       }
    };
-   auto load_O = [&](const int64_t e, const int64_t bt)
+   auto load_O = [&](const int64_t e, const int64_t bt, const int qz0 = 0, const int qz1 = Q)
    {
       if (ABL == 2)
       {
@@ -250,6 +242,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
 #pragma unroll
             for (int qz = 0; qz < Q; qz++)
             {
+               if (qz < qz0 || qz >= qz1) { continue; }
 #pragma unroll
                for (int cp = 0; cp < 3; cp++)
                {
@@ -262,7 +255,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
          {
             const double *Db = Dq + (VEC ? comp*va.d_comp_stride : 0) + bt*(int64_t)(Q*NBZ*QQ) + tz*QQ + b*Q + a;
 #pragma unroll
-            for (int qz = 0; qz < Q; qz++) { O[qz][0] = Db[qz*(NBZ*QQ)]; }
+            for (int qz = 0; qz < Q; qz++) { if (qz >= qz0 && qz < qz1) { O[qz][0] = Db[qz*(NBZ*QQ)]; } }
          }
          return;
       }
@@ -272,6 +265,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
 #pragma unroll
       for (int qz = 0; qz < Q; qz++)
       {
+         if (qz < qz0 || qz >= qz1) { continue; }
 #pragma unroll
          for (int c = 0; c < NC; c++) { O[qz][c] = De[c*Q3 + qz*QQ]; }
       }
@@ -1079,11 +1073,7 @@ static int launch_apply_vec(int64_t ne, const double *B, const double *G, const 
                             const double *x, const int *gmap, double *yE, VecArgs va, hipStream_t s)
 {
    constexpr int NBZ = nbz_for(Q);
-#ifdef MFA_VEC_RB
-   constexpr int RBV = Q > 3 ? MFA_VEC_RB : 0;
-#else
    constexpr int RBV = Q > 3 ? rb_table(KIND, D, Q) : 0;
-#endif
    auto kern = k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM, BLK, 0, false, 0, RBV, true>;
    BasisT<D*Q> bg;
    fill_basis(bg, D, Q, B, G);
