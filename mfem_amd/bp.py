@@ -1,6 +1,7 @@
 """CEED bake-off problem driver on the C ABI (device-resident), the Python twin of
 tests/benchmarks/bench_ceed.cpp `BakeOff`/`Problem`/`Kernel`: Cartesian hex mesh, H1 order
-p, BP1 (mass) / BP3 (diffusion, GL) / BP5 (diffusion, GLL), all-boundary Dirichlet,
+p, BP1 (mass) / BP3 (diffusion, GL) / BP5 (diffusion, GLL) and their vector versions BP2 / BP4 /
+BP6 (vdim = 3, Ordering::byVDIM as bench_ceed.cpp:47; serial only), all-boundary Dirichlet,
 Jacobi-PCG.  Serial, or one box per rank with the exchange of mfem_amd/parallel.py.
 torch supplies device memory and the stream; every computation is a HIP kernel of
 libmfem_amd.so."""
@@ -28,13 +29,18 @@ class BakeoffProblem:
         pr = self.prob
         self.kind, self.D, self.Q, self.B, self.G, Bn, Gn, W = bakeoff_tables(problem, p)
         kind, D, Q = self.kind, self.D, self.Q
+        self.vdim = 3 if problem in ("bp2", "bp4", "bp6") else 0
+        if self.vdim and (part is not None and exchange is not None):
+            raise ValueError("the vector problems are built for one GPU (the partitioned path is scalar)")
+        vd = max(1, self.vdim)
         # nodal space of the mesh: trilinear for the synthetic boxes, order Dn-1 for mesh files
         self.Dn = getattr(pr, "Dn", 2)
         if self.Dn != 2:
             from .tables import gauss_legendre, gauss_lobatto, lagrange_tables
-            qx, _ = gauss_lobatto(Q) if problem == "bp5" else gauss_legendre(Q)
+            qx, _ = gauss_lobatto(Q) if problem in ("bp5", "bp6") else gauss_legendre(Q)
             Bn, Gn = lagrange_tables(gauss_lobatto(self.Dn)[0], qx)
-        self.ne, self.ndofs = pr.ne, pr.ndofs
+        self.ne, self.nscalar = pr.ne, pr.ndofs
+        self.ndofs = pr.ndofs*vd                      # unknowns (vdofs of a vector problem)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
         self.stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
         self.gm, self.off, self.ind = t(pr.gather_map), t(pr.offsets), t(pr.indices)
@@ -42,21 +48,26 @@ class BakeoffProblem:
         self.pa = torch.zeros(capi.lib.mfem_amd_pa_data_size(kind, layout, Q, self.ne), dtype=torch.float64, device=self.dev)
         capi.call("mfem_amd_pa_setup_from_nodes_3d", kind, self.Dn, Q, 1, self.ne, Bn, Gn, _p(Wd), _p(nodesE), _p(one), 1,
                   layout, _p(self.pa), None, self.stream)
-        self.yE = torch.empty(self.ne*D**3, dtype=torch.float64, device=self.dev)
-        # essential dofs: all six faces of the global box (bench_ceed.cpp:99-100)
+        self.yE = torch.empty(self.ne*D**3*vd, dtype=torch.float64, device=self.dev)
+        # essential dofs: all six faces of the global box (bench_ceed.cpp:99-100), every component
         if part is not None:
             marker, ess = part.essential_marker()
         else:
             ess = pr.boundary_dofs()
-            marker = np.zeros(self.ndofs, np.uint8); marker[ess] = 1
+            marker = np.zeros(self.nscalar, np.uint8); marker[ess] = 1
+        if self.vdim:
+            ess = (ess.astype(np.int64)[:, None]*vd + np.arange(vd)[None, :]).reshape(-1)      # byVDIM vdofs
+            marker = np.repeat(marker, vd)
         self.ess_host = ess
         self.ess, self.marker = t(ess.astype(np.int32)), t(marker)
-        self.masked = torch.empty(self.ne*D**3, dtype=torch.int32, device=self.dev)
-        capi.call("mfem_amd_mask_gather_map", self.ne*D**3, _p(self.gm), _p(self.marker), _p(self.masked), self.stream)
+        self.masked = None
+        if not self.vdim:       # vector spaces apply the marker in the gather instead
+            self.masked = torch.empty(self.ne*D**3, dtype=torch.int32, device=self.dev)
+            capi.call("mfem_amd_mask_gather_map", self.ne*D**3, _p(self.gm), _p(self.marker), _p(self.masked), self.stream)
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
-        self.op = capi.PaOperator(kind, layout, D, Q, self.ne, self.ndofs, vp(self.B), vp(self.G), _p(self.pa),
+        self.op = capi.PaOperator(kind, layout, D, Q, self.ne, self.nscalar, vp(self.B), vp(self.G), _p(self.pa),
                                   _p(self.gm), _p(self.masked), _p(self.off), _p(self.ind), len(ess), _p(self.ess),
-                                  _p(self.marker), _p(self.yE))
+                                  _p(self.marker), _p(self.yE), self.vdim, 1 if self.vdim else 0, 0)
         self.ghost = t(part.ext_ldof) if part is not None else None
         self._dinv = None
         self._ws = None
@@ -64,10 +75,18 @@ class BakeoffProblem:
 
     # ---- BilinearForm::Mult (unconstrained L->L), the BK "Kernel" of bench_ceed.cpp:163-190
     def l2e(self, x):
+        if self.vdim:
+            capi.call("mfem_amd_pa_apply_L2E_vdim", self.kind, self.layout, self.D, self.Q, self.ne, self.vdim, 1, self.nscalar,
+                      self.B, self.G, _p(self.pa), 0, _p(self.gm), None, _p(x), _p(self.yE), self.stream)
+            return
         capi.call("mfem_amd_pa_apply_L2E", self.kind, self.layout, self.D, self.Q, self.ne, self.B, self.G, _p(self.pa),
                   _p(self.gm), _p(x), _p(self.yE), self.stream)
 
     def e2l(self, y):
+        if self.vdim:
+            capi.call("mfem_amd_restrict_scatter_vdim", self.nscalar, self.D**3, self.vdim, 1, _p(self.off), _p(self.ind),
+                      _p(self.yE), _p(y), 0, 0, self.stream)
+            return
         capi.call("mfem_amd_restrict_scatter", self.ndofs, _p(self.off), _p(self.ind), _p(self.yE), _p(y), 0, 0, self.stream)
 
     def mult(self, x, y):
@@ -84,14 +103,19 @@ class BakeoffProblem:
     def dinv(self):
         if self._dinv is None:
             dE = torch.zeros(self.ne*self.D**3, dtype=torch.float64, device=self.dev)
-            diag = torch.empty(self.ndofs, dtype=torch.float64, device=self.dev)
+            diag = torch.empty(self.nscalar, dtype=torch.float64, device=self.dev)
             if self.kind:
                 capi.call("mfem_amd_pa_diffusion_diag_3d", self.D, self.Q, self.ne, 1, self.B, self.G, _p(self.pa),
                           self.layout, _p(dE), self.stream)
             else:
                 capi.call("mfem_amd_pa_mass_diag_3d", self.D, self.Q, self.ne, self.B, _p(self.pa), self.layout, _p(dE),
                           self.stream)
-            capi.call("mfem_amd_restrict_scatter", self.ndofs, _p(self.off), _p(self.ind), _p(dE), _p(diag), 0, 1, self.stream)
+            capi.call("mfem_amd_restrict_scatter", self.nscalar, _p(self.off), _p(self.ind), _p(dE), _p(diag), 0, 1, self.stream)
+            if self.vdim:           # scalar coefficient: every component carries the scalar diagonal
+                dv = torch.empty(self.ndofs, dtype=torch.float64, device=self.dev)
+                capi.call("mfem_amd_vec_replicate_vdim", self.nscalar, self.vdim, 1, None, _p(diag), _p(dv), self.stream)
+                torch.cuda.current_stream(self.dev).synchronize()
+                diag = dv
             if self.ex is not None:                 # ParBilinearForm::AssembleDiagonal: one P^T exchange
                 self.ex.reverse(diag.data_ptr(), self.stream)
                 if self.ghost.numel():              # keep 1/0 out of the ghost entries
@@ -120,10 +144,16 @@ class BakeoffProblem:
         Wd, nodesE = t(W), t(self.prob.nodes_E)      # keep the device tensors alive across the launch
         capi.call("mfem_amd_pa_setup_from_nodes_3d", 0, self.Dn, Qm, 1, self.ne, Bn, Gn, _p(Wd), _p(nodesE), _p(one),
                   1, 0, _p(pam), None, self.stream)
-        ones = torch.ones(self.ndofs, dtype=torch.float64, device=self.dev)
+        ones = torch.ones(self.nscalar, dtype=torch.float64, device=self.dev)
         b = torch.empty_like(ones)
         capi.call("mfem_amd_pa_apply_L2E", 0, 0, self.D, Qm, self.ne, Bm, Gm, _p(pam), _p(self.gm), _p(ones), _p(self.yE), self.stream)
-        self.e2l(b)
+        capi.call("mfem_amd_restrict_scatter", self.nscalar, _p(self.off), _p(self.ind), _p(self.yE), _p(b), 0, 0, self.stream)
+        if self.vdim:               # f = (1,1,1)/sqrt(3) (bench_ceed.cpp:54): the scalar form on every component
+            bv = torch.empty(self.ndofs, dtype=torch.float64, device=self.dev)
+            sc = np.full(self.vdim, 1.0/np.sqrt(float(self.vdim)))
+            capi.call("mfem_amd_vec_replicate_vdim", self.nscalar, self.vdim, 1, sc.ctypes.data_as(C.c_void_p), _p(b), _p(bv), self.stream)
+            torch.cuda.current_stream(self.dev).synchronize()
+            b = bv
         if self.ex is not None:
             self.ex.reverse(b.data_ptr(), self.stream)
         capi.call("mfem_amd_set_subvector", self.ess.numel(), _p(self.ess), None, 0.0, _p(b), self.stream)

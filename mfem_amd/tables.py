@@ -36,6 +36,8 @@ def lagrange_tables(nodes, pts):
 def bakeoff_tables(problem, p):
     """(kind, D1D, Q1D, B, G, Bn, Gn, W) of CEED BP1/BP3 (Gauss-Legendre, Q = p+2) and BP5
     (Gauss-Lobatto, Q = p+1), tests/benchmarks/bench_ceed.cpp:45-51,144-160."""
+    # bp2 / bp4 / bp6 are the vector (vdim = 3) versions of bp1 / bp3 / bp5: same tables
+    problem = {"bp2": "bp1", "bp4": "bp3", "bp6": "bp5"}.get(problem, problem)
     kind = 0 if problem == "bp1" else 1
     D = p + 1
     if problem == "bp5":

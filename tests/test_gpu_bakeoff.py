@@ -117,3 +117,29 @@ def test_operator_properties_at_scale():
         A2 = torch.empty_like(x)
         bp.mult(x, A2)
         assert torch.equal(A2, Ax)                                                           # bit-reproducible
+
+
+ANCH_VEC = json.loads((Path(__file__).parent / "golden" / "baseline_anchors_vec.json").read_text())
+
+
+@pytest.mark.parametrize("case", ANCH_VEC["cases"], ids=lambda c: f"{c['problem']}_p{c['p']}")
+def test_vector_bakeoff_known_answers(case):
+    """BP2 / BP4 / BP6 (vdim = 3) through the Python driver: unknown count, |B|, Jacobi-PCG iterations and |X|
+    against the reference's values (oracle/ref_probe_vec.cpp); all invariant under the dof permutation between
+    MFEM's numbering and the driver's."""
+    from mfem_amd import capi
+    from mfem_amd.bp import BakeoffProblem
+    capi.call("mfem_amd_init", 0)
+    p, n = case["p"], case["N"]
+    bp = BakeoffProblem(case["problem"], p, (n, n, n), "cuda:0")
+    assert (bp.ne, bp.ndofs, bp.D, bp.Q) == (case["NE"], case["dofs"], case["D1D"], case["Q1D"])
+    b = bp.rhs_unit_source()
+    nB = float(torch.linalg.vector_norm(b).item())
+    assert abs(nB - case["norm_B"]) < 1e-12*case["norm_B"]
+    X, res, hist = bp.pcg(b, 1e-12, max_iter=2000, check_every=16, want_hist=True)
+    torch.cuda.synchronize()
+    nX = float(torch.linalg.vector_norm(X).item())
+    assert abs(nX - case["norm_X"]) < 1e-8*case["norm_X"], (nX, case["norm_X"])
+    assert res.converged == 1
+    # rel tol 1e-12: the last decision sits in rounding noise (see test_bakeoff_known_answers)
+    assert abs(res.iterations - case["pcg_its"]) <= max(1, case["pcg_its"]//10), (res.iterations, case["pcg_its"])
