@@ -85,9 +85,10 @@ def main():
     t0 = time.perf_counter()
     if world > 1:
         part = BoxPartition(p, (n, n, n), pg, rank)
-        ex = Exchange(part, dev)
+        vd = 3 if args.problem in ("bp2", "bp4", "bp6") else 1
+        ex = Exchange(part, dev, vdim=vd if vd > 1 else 0)
         bp = BakeoffProblem(args.problem, p, (n, n, n), dev, part=part, exchange=ex)
-        owned = torch.tensor([part.n_owned], dtype=torch.float64, device=dev)
+        owned = torch.tensor([part.n_owned*vd], dtype=torch.float64, device=dev)
         dist.all_reduce(owned)
         total_dofs = int(owned.item())
     else:

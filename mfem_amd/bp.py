@@ -1,7 +1,7 @@
 """CEED bake-off problem driver on the C ABI (device-resident), the Python twin of
 tests/benchmarks/bench_ceed.cpp `BakeOff`/`Problem`/`Kernel`: Cartesian hex mesh, H1 order
 p, BP1 (mass) / BP3 (diffusion, GL) / BP5 (diffusion, GLL) and their vector versions BP2 / BP4 /
-BP6 (vdim = 3, Ordering::byVDIM as bench_ceed.cpp:47; serial only), all-boundary Dirichlet,
+BP6 (vdim = 3, Ordering::byVDIM as bench_ceed.cpp:47; in parallel the Exchange is built with vdim = 3), all-boundary Dirichlet,
 Jacobi-PCG.  Serial, or one box per rank with the exchange of mfem_amd/parallel.py.
 torch supplies device memory and the stream; every computation is a HIP kernel of
 libmfem_amd.so."""
@@ -30,8 +30,6 @@ class BakeoffProblem:
         self.kind, self.D, self.Q, self.B, self.G, Bn, Gn, W = bakeoff_tables(problem, p)
         kind, D, Q = self.kind, self.D, self.Q
         self.vdim = 3 if problem in ("bp2", "bp4", "bp6") else 0
-        if self.vdim and (part is not None and exchange is not None):
-            raise ValueError("the vector problems are built for one GPU (the partitioned path is scalar)")
         vd = max(1, self.vdim)
         # nodal space of the mesh: trilinear for the synthetic boxes, order Dn-1 for mesh files
         self.Dn = getattr(pr, "Dn", 2)
@@ -68,7 +66,12 @@ class BakeoffProblem:
         self.op = capi.PaOperator(kind, layout, D, Q, self.ne, self.nscalar, vp(self.B), vp(self.G), _p(self.pa),
                                   _p(self.gm), _p(self.masked), _p(self.off), _p(self.ind), len(ess), _p(self.ess),
                                   _p(self.marker), _p(self.yE), self.vdim, 1 if self.vdim else 0, 0)
-        self.ghost = t(part.ext_ldof) if part is not None else None
+        self.ghost = None
+        if part is not None:
+            g = np.asarray(part.ext_ldof, np.int64)
+            if self.vdim:
+                g = (g[:, None]*vd + np.arange(vd)[None, :]).reshape(-1)
+            self.ghost = t(g.astype(np.int32))
         self._dinv = None
         self._ws = None
         self._comm = None

@@ -357,13 +357,21 @@ static int constrained_mult(const mfem_amd_pa_operator *op, const mfem_amd_comm 
    if (op->vdim > 0)
    {
       // vector space: the essential marker is applied in the gather, rows are vdofs
-      MFA_REQUIRE(!comm, "pa operator: the partitioned path is built for scalar spaces only");
       MFA_REQUIRE(op->gather_map, "pa operator: gather_map is NULL");
+      if (comm)
+      {
+         if (int rc = comm->forward(comm->ctx, x, (void*)s)) { set_error("comm forward exchange failed (%d)", rc); return rc; }
+      }
       const VecArgs va = {op->vdim, op->byvdim ? 1 : 0, op->ndofs, ess ? op->ess_marker : nullptr, op->pa_comp_stride, 0};
       if (int rc = pa_apply_L2E_vec(op->kind, op->pa_layout, op->D1D, op->Q1D, op->ne, op->B, op->G, op->pa_data,
                                     op->gather_map, x, op->yE, va, s)) { return rc; }
-      return scatter_dot_vec(op->ndofs, op->D1D*op->D1D*op->D1D, op->vdim, op->byvdim ? 1 : 0, op->offsets, op->indices,
-                             op->yE, y, ess ? op->ess_marker : nullptr, x, w, partials, nb, skip, s);
+      if (int rc = scatter_dot_vec(op->ndofs, op->D1D*op->D1D*op->D1D, op->vdim, op->byvdim ? 1 : 0, op->offsets, op->indices,
+                                   op->yE, y, ess ? op->ess_marker : nullptr, x, w, partials, nb, skip, s)) { return rc; }
+      if (comm)
+      {
+         if (int rc = comm->reverse(comm->ctx, y, (void*)s)) { set_error("comm reverse exchange failed (%d)", rc); return rc; }
+      }
+      return 0;
    }
    const int *gm = ess ? op->masked_gather_map : op->gather_map;
    MFA_REQUIRE(gm, "pa operator: %s is NULL", ess ? "masked_gather_map" : "gather_map");

@@ -234,12 +234,27 @@ class GeneralPartition:
         return m, ess
 
 
+class _VdofView:
+    """The shared-dof tables of a partition expanded from dofs to the vdofs of a byVDIM vector space."""
+
+    def __init__(self, part, vd):
+        ex = lambda ids: (np.asarray(ids, np.int64)[:, None]*vd + np.arange(vd)[None, :]).reshape(-1).astype(np.int32)
+        self.upper = [(r, ex(ids)) for r, ids in part.upper]
+        self.lower = [(r, ex(ids)) for r, ids in part.lower]
+        self.prob = part.prob
+        _finish_shared_tables(self, part.prob.ndofs*vd)
+
+
 class Exchange:
     """P / P^T / all-reduce on top of torch.distributed.  `device` is a torch device; with
     CPU tensors (tests) the index kernels are torch ops, with CUDA tensors they are the HIP
     kernels of the C ABI called on raw pointers."""
 
-    def __init__(self, part, device, group=None):
+    def __init__(self, part, device, group=None, vdim=0):
+        """vdim > 0: the vectors are those of a vector space ordered byVDIM (vdof = dof*vdim + c): every
+        shared dof carries vdim consecutive entries."""
+        if vdim:
+            part = _VdofView(part, vdim)
         self.part, self.device, self.group = part, torch.device(device), group
         self.on_gpu = self.device.type == "cuda"
         self.stage = self.on_gpu and dist.is_initialized() and dist.get_backend(group) == "gloo"

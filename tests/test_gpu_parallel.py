@@ -38,7 +38,8 @@ def _worker(rank, world, port, problem, p, n, out, mode="box"):
                     else MeshTables.from_cartesian(CartesianProblem(p, 2*n, n, n + 1)))
             pv = np.random.default_rng(5).integers(0, world, tabs.ne).astype(np.int32)
             part = GeneralPartition(tabs, pv, rank)
-        ex = Exchange(part, "cuda:0")
+        vd = 3 if problem in ("bp2", "bp4", "bp6") else 1          # vector problems: vdofs, byVDIM
+        ex = Exchange(part, "cuda:0", vdim=vd if vd > 1 else 0)
         bp = BakeoffProblem(problem, p, (n, n, n), "cuda:0", part=part, exchange=ex)
         b = bp.rhs_unit_source()
         X, res, hist = bp.pcg(b, 1e-10, max_iter=1000, check_every=4, want_hist=True)
@@ -50,6 +51,10 @@ def _worker(rank, world, port, problem, p, n, out, mode="box"):
         Xs, rs, hs = sp.pcg(sp.rhs_unit_source(), 1e-10, max_iter=1000, check_every=4, want_hist=True)
         torch.cuda.synchronize()
         l2g, _ = part.local_to_global()
+        ghost_mask = part.ghost
+        if vd > 1:
+            l2g = (np.asarray(l2g, np.int64)[:, None]*vd + np.arange(vd)[None, :]).reshape(-1)
+            ghost_mask = np.repeat(part.ghost, vd)
         assert res.iterations == rs.iterations, (res.iterations, rs.iterations)
         Xs_l = Xs.cpu().numpy()[l2g]
         err = np.max(np.abs(X.cpu().numpy() - Xs_l))/np.max(np.abs(Xs_l))
@@ -63,7 +68,7 @@ def _worker(rank, world, port, problem, p, n, out, mode="box"):
         xl[bp.ghost.long()] = 0.0
         yl = torch.empty_like(xl); bp.mult(xl, yl)
         torch.cuda.synchronize()
-        own = ~part.ghost
+        own = ~ghost_mask
         e2 = np.max(np.abs(yl.cpu().numpy()[own] - ys.cpu().numpy()[l2g][own]))/float(ys.abs().max())
         assert e2 < 1e-12, e2
         out.put((rank, "ok"))
@@ -75,7 +80,7 @@ def _worker(rank, world, port, problem, p, n, out, mode="box"):
 
 
 @pytest.mark.parametrize("problem,p,n,mode", [("bp3", 3, 4, "box"), ("bp1", 2, 5, "box"), ("bp3", 2, 3, "random"),
-                                              ("bp3", 3, 0, "toroid")])
+                                              ("bp3", 3, 0, "toroid"), ("bp4", 2, 3, "box"), ("bp2", 3, 2, "random")])
 def test_two_ranks_match_serial(problem, p, n, mode):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
