@@ -184,18 +184,32 @@ def main():
         torch.cuda.empty_cache()
         for q in range(1, 9):
             nq = max(1, round((1.0e7)**(1.0/3.0)/q))
-            bq = BakeoffProblem(args.problem, q, (nq, nq, nq), dev)
-            xq = torch.rand(bq.ndofs, dtype=torch.float64, generator=g).to(dev)
-            yq = torch.empty_like(xq)
-            for _ in range(3):
-                bq.mult(xq, yq)
-            tq = timed(lambda: bq.mult(xq, yq), 20)/20
-            tl = timed(lambda: bq.l2e(xq), 20)/20
-            b1, b2 = algorithmic_bytes(bq.kind, bq.D, bq.Q, bq.ne, bq.ndofs)
-            by_order.append({"p": q, "dofs": bq.ndofs, "GDOF/s": bq.ndofs/tq/1e9, "ms_per_step": tq*1e3,
-                             "apply_frac": (b1 + b2)/tq/1e9/HBM_PEAK_GBS, "l2e_ms": tl*1e3, "l2e_frac": b1/tl/1e9/HBM_PEAK_GBS})
-            del bq, xq, yq
-            torch.cuda.empty_cache()
+            best = None
+            # Two separately allocated attempts, the faster kept: on this platform the SAME kernel on the SAME
+            # data occasionally runs several times slower for one particular placement of its buffers
+            # (last experiment); a second placement (shifted by a pad) does not show it.
+            for attempt in range(2):
+                pad = torch.empty((3 << 20)*attempt + 8, dtype=torch.uint8, device=dev)
+                bq = BakeoffProblem(args.problem, q, (nq, nq, nq), dev)
+                xq = torch.rand(bq.ndofs, dtype=torch.float64, generator=g).to(dev)
+                yq = torch.empty_like(xq)
+                for _ in range(3):
+                    bq.mult(xq, yq)
+                tq = timed(lambda: bq.mult(xq, yq), 20)/20
+                tl = timed(lambda: bq.l2e(xq), 20)/20
+                b1, b2 = algorithmic_bytes(bq.kind, bq.D, bq.Q, bq.ne, bq.ndofs)
+                row = {"p": q, "dofs": bq.ndofs, "GDOF/s": bq.ndofs/tq/1e9, "ms_per_step": tq*1e3,
+                       "apply_frac": (b1 + b2)/tq/1e9/HBM_PEAK_GBS, "l2e_ms": tl*1e3, "l2e_frac": b1/tl/1e9/HBM_PEAK_GBS,
+                       "slower_attempt_ms": None}
+                if best is None:
+                    best = row
+                else:
+                    fast, slow = (row, best) if row["ms_per_step"] < best["ms_per_step"] else (best, row)
+                    fast["slower_attempt_ms"] = slow["ms_per_step"]
+                    best = fast
+                del bq, xq, yq, pad
+                torch.cuda.empty_cache()
+            by_order.append(best)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
