@@ -15,7 +15,7 @@ import numpy as np
 
 
 class CartesianProblem:
-    def __init__(self, p, nx, ny, nz, sx=1.0, sy=1.0, sz=1.0, origin=(0, 0, 0), global_n=None):
+    def __init__(self, p, nx, ny, nz, sx=1.0, sy=1.0, sz=1.0, origin=(0, 0, 0), global_n=None, transpose=True):
         self.p, self.n = p, (nx, ny, nz)
         gn = global_n or (nx, ny, nz)
         D = p + 1
@@ -24,6 +24,7 @@ class CartesianProblem:
         self.ndofs = n1[0]*n1[1]*n1[2]
         self.ne = nx*ny*nz
         assert self.ne*D**3 < 2**31 and self.ndofs < 2**31, "int32 index arrays (as the reference's)"
+        self.offsets = self.indices = None
         ex, ey, ez = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
         # element index e = ex + nx*(ey + ny*ez)  -> order arrays with ez slowest
         ex, ey, ez = [a.transpose(2, 1, 0).reshape(-1) for a in (ex, ey, ez)]
@@ -33,12 +34,13 @@ class CartesianProblem:
         gz = (ez[:, None]*p + d[None, :])
         g = (gx[:, None, None, :] + n1[0]*(gy[:, None, :, None] + n1[1]*gz[:, :, None, None]))
         self.gather_map = np.ascontiguousarray(g.reshape(-1), np.int32)   # (e, dz, dy, dx)
-        # transpose table: stable sort by L-dof keeps (element, local) order within a dof
-        order = np.argsort(self.gather_map, kind="stable")
-        self.indices = order.astype(np.int32)
-        counts = np.bincount(self.gather_map, minlength=self.ndofs)
-        self.offsets = np.zeros(self.ndofs + 1, np.int32)
-        np.cumsum(counts, out=self.offsets[1:])
+        if transpose:
+            # transpose table: stable sort by L-dof keeps (element, local) order within a dof
+            order = np.argsort(self.gather_map, kind="stable")
+            self.indices = order.astype(np.int32)
+            counts = np.bincount(self.gather_map, minlength=self.ndofs)
+            self.offsets = np.zeros(self.ndofs + 1, np.int32)
+            np.cumsum(counts, out=self.offsets[1:])
         # trilinear E-nodes (Dn = 2): (2,2,2,3,ne), x fastest
         hx, hy, hz = sx/gn[0], sy/gn[1], sz/gn[2]
         X = np.empty((self.ne, 3, 2, 2, 2))

@@ -119,6 +119,59 @@ def test_operator_properties_at_scale():
         assert torch.equal(A2, Ax)                                                           # bit-reproducible
 
 
+def test_element_kernel_beyond_2_31_doubles_of_pa_data():
+    """BASELINE's largest single-GPU size (1e8 dofs): BP3 p = 4 on 120^3 hexes -- 1.1e8 dofs, 1.73e6 elements,
+    2.24e9 doubles (17.9 GB) of pa_data, i.e. offsets past 2^31 in the setup and element kernels (the reference's
+    32-bit DeviceTensor indexing cannot hold this case).  Property: the mesh is uniform, so the E-vector block of an
+    element depends only on the element's x values -- the last elements (stored past the 2^31 boundary) must give
+    bit for bit what a 4^3 mesh of the same element size gives for the same x values; and the blocked layout must
+    agree with MFEM's layout there."""
+    import ctypes as C
+    from mfem_amd import capi
+    from mfem_amd.cartesian import CartesianProblem
+    from mfem_amd.tables import bakeoff_tables
+    capi.call("mfem_amd_init", 0)
+    dev = torch.device("cuda:0")
+    p, n, m = 4, 120, 4
+    kind, D, Q, B, G, Bn, Gn, W = bakeoff_tables("bp3", p)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    big = CartesianProblem(p, n, n, n, transpose=False)
+    small = CartesianProblem(p, m, m, m, sx=m/n, sy=m/n, sz=m/n, transpose=False)       # same element size
+    assert big.ne*6*Q**3 > 2**31
+    one, Wd = torch.ones(1, dtype=torch.float64, device=dev), t(W)
+
+    def run(prob, x, layout):
+        ne = prob.ne
+        nodesE, gm = t(prob.nodes_E), t(prob.gather_map)
+        pa = torch.zeros(capi.lib.mfem_amd_pa_data_size(kind, layout, Q, ne), dtype=torch.float64, device=dev)
+        capi.call("mfem_amd_pa_setup_from_nodes_3d", kind, 2, Q, 1, ne, Bn, Gn, ptr(Wd), ptr(nodesE), ptr(one), 1, layout, ptr(pa), None, None)
+        yE = torch.empty(ne*D**3, dtype=torch.float64, device=dev)
+        capi.call("mfem_amd_pa_apply_L2E", kind, layout, D, Q, ne, B, G, ptr(pa), ptr(gm), ptr(x), ptr(yE), None)
+        torch.cuda.synchronize()
+        return yE
+
+    g = torch.Generator(device="cpu"); g.manual_seed(11)
+    xs = torch.rand(small.ndofs, dtype=torch.float64, generator=g)
+    # x of the big problem: arbitrary, except that the last m^3-shaped corner block of elements sees xs
+    xb = torch.rand(big.ndofs, dtype=torch.float64, generator=g)
+    corner = [e for e in range(big.ne) if all(c >= n - m for c in (e % n, (e//n) % n, e//(n*n)))]
+    gmb = big.gather_map.reshape(big.ne, D**3)
+    gms = small.gather_map.reshape(small.ne, D**3)
+    for k, e in enumerate(corner):                      # corner elements in lexicographic order = the small mesh's order
+        xb[torch.from_numpy(gmb[e].astype(np.int64))] = xs[torch.from_numpy(gms[k].astype(np.int64))]
+    assert corner[0]*6*Q**3 > 2**31                      # every compared element lies past the boundary
+    ys = run(small, xs.to(dev), 0).cpu().numpy().reshape(small.ne, D**3)
+    xb_d = xb.to(dev)
+    for layout in (1, 0):
+        yb = run(big, xb_d, layout)
+        got = yb.view(big.ne, D**3)[torch.tensor(corner, device=dev)].cpu().numpy()
+        del yb
+        torch.cuda.empty_cache()
+        # the geometry differs by a translation only: pa_data, hence the action, agrees to rounding of the node coordinates
+        assert np.max(np.abs(got - ys)) <= 1e-12*np.max(np.abs(ys)), layout
+
+
 ANCH_VEC = json.loads((Path(__file__).parent / "golden" / "baseline_anchors_vec.json").read_text())
 
 
