@@ -132,3 +132,39 @@ def test_ex1p_driver_two_ranks_equals_one_rank_and_serial_ex1():
     # (2e-5 relative ten orders below the start); the first iterations agree to the 6 printed digits
     assert np.all(np.abs(h1[big] - h_ser[big]) <= 1e-3*h_ser[big]) and np.all(np.abs(h2[big] - h_ser[big]) <= 1e-3*h_ser[big])
     assert np.all(np.abs(h1[:6] - h_ser[:6]) <= 2e-6*h_ser[:6]) and np.all(np.abs(h2[:6] - h_ser[:6]) <= 2e-6*h_ser[:6])
+
+
+_NCCL_ONE = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["MFEM_AMD_ROOT"])
+from mfem_amd import capi
+from mfem_amd.bp import BakeoffProblem
+from mfem_amd.parallel import BoxPartition, Exchange
+torch.cuda.set_device(0)
+capi.call("mfem_amd_init", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+part = BoxPartition(3, (6, 6, 6), (1, 1, 1), 0)
+ex = Exchange(part, "cuda:0")
+bp = BakeoffProblem("bp3", 3, (6, 6, 6), "cuda:0", part=part, exchange=ex)
+X, res, hist = bp.pcg(bp.rhs_unit_source(), 1e-10, max_iter=500, check_every=4, want_hist=True)
+sp = BakeoffProblem("bp3", 3, (6, 6, 6), "cuda:0")
+Xs, rs, hs = sp.pcg(sp.rhs_unit_source(), 1e-10, max_iter=500, check_every=4, want_hist=True)
+t = torch.ones(1, dtype=torch.float64, device="cuda:0"); dist.all_reduce(t); dist.barrier()
+torch.cuda.synchronize()
+assert res.iterations == rs.iterations and res.converged == 1, (res.iterations, rs.iterations)
+assert float((X - Xs).abs().max()) <= 1e-12*float(Xs.abs().max())
+dist.destroy_process_group()
+print("nccl-one ok", res.iterations)
+"""
+
+
+def test_rccl_backend_world_of_one():
+    """The RCCL ("nccl") transport on the real device with a world of one rank: communicator creation, the
+    device-side all-reduce of the PCG scalars issued from the C callbacks, stream ordering.  (Eight-GPU runs are
+    the driver's; two ranks cannot share one GPU under RCCL -- the gloo tests above cover the exchange itself.)"""
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + os.getpid() % 90), MFEM_AMD_ROOT=str(ROOT),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _NCCL_ONE], capture_output=True, text=True, timeout=280, env=env, cwd=str(ROOT))
+    assert r.returncode == 0 and "nccl-one ok" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
