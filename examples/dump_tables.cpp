@@ -31,6 +31,33 @@ static double smix(uint64_t seed, uint64_t i)
 }
 static double coef_fn(const Vector &x) { return 1.0 + x(0)*x(0) + x(1)*x(2); }
 
+// the coefficient functions of tests/golden/mat (oracle/ref_dump_mat.cpp evaluates the same expressions
+// through the reference's classes)
+static void vec_fn(const Vector &x, Vector &v)
+{
+   v(0) = 1.0 + x(0)*x(0); v(1) = 2.0 + x(1)*x(2); v(2) = 1.5 + 0.5*x(0)*x(2);
+}
+static void sym_entries(const Vector &x, double *m)
+{
+   m[0] = 2.0 + x(0)*x(0); m[1] = 0.3*x(1); m[2] = 0.2*x(0)*x(2);
+   m[3] = 3.0 + x(1)*x(1); m[4] = -0.4*x(2); m[5] = 2.5 + x(0)*x(1);
+}
+static void sym_fn(const Vector &x, DenseSymmetricMatrix &K)
+{
+   K.SetSize(3);
+   double m[6]; sym_entries(x, m);
+   K(0,0) = m[0]; K(0,1) = m[1]; K(0,2) = m[2]; K(1,1) = m[3]; K(1,2) = m[4]; K(2,2) = m[5];
+}
+static void mat_fn(const Vector &x, DenseMatrix &K)
+{
+   K.SetSize(3);
+   double m[6]; sym_entries(x, m);
+   const double s1 = 0.7 + 0.1*x(0), s2 = -0.5*x(1), s3 = 0.25 + 0.2*x(2);
+   K(0,0) = m[0];      K(0,1) = m[1] + s1; K(0,2) = m[2] + s2;
+   K(1,0) = m[1] - s1; K(1,1) = m[3];      K(1,2) = m[4] + s3;
+   K(2,0) = m[2] - s2; K(2,1) = m[4] - s3; K(2,2) = m[5];
+}
+
 int main(int argc, char **argv)
 {
    if (argc < 4) { std::cerr << "usage: see the header of dump_tables.cpp\n"; return 2; }
@@ -107,10 +134,26 @@ int main(int argc, char **argv)
       ConstantCoefficient one(1.0);
       FunctionCoefficient fc(coef_fn);
       Coefficient &Q = varcoef ? (Coefficient&)fc : (Coefficient&)one;
+      // <varcoef> 2..6: diffusion with a vector function / symmetric matrix constant / symmetric matrix
+      // function / matrix constant / matrix function coefficient (the cases of tests/golden/mat)
+      const int ctype = atoi(argv[a+3]) - 2;
+      Vector mid(3); mid(0) = 0.4; mid(1) = 0.3; mid(2) = 0.6;
+      DenseSymmetricMatrix Ks; sym_fn(mid, Ks);
+      DenseMatrix Km; mat_fn(mid, Km);
+      VectorFunctionCoefficient vq(3, vec_fn);
+      SymmetricMatrixConstantCoefficient smc(Ks);
+      SymmetricMatrixFunctionCoefficient smf(3, sym_fn);
+      MatrixConstantCoefficient mc(Km);
+      MatrixFunctionCoefficient mf(3, mat_fn);
+      MatrixCoefficient *MQs[5] = { nullptr, &smc, &smf, &mc, &mf };
+      const bool nonsym = ctype >= 3;
       BilinearForm bf(&fes);
       bf.SetAssemblyLevel(AssemblyLevel::PARTIAL);
-      BilinearFormIntegrator *bfi = (kind == 0) ? (BilinearFormIntegrator*)new MassIntegrator(Q, rule == 2 ? nullptr : ir)
-                                    : (BilinearFormIntegrator*)new DiffusionIntegrator(Q, rule == 2 ? nullptr : ir);
+      const IntegrationRule *irp = rule == 2 ? nullptr : ir;
+      BilinearFormIntegrator *bfi = (kind == 0) ? (BilinearFormIntegrator*)new MassIntegrator(Q, irp)
+                                    : ctype == 0 ? (BilinearFormIntegrator*)new DiffusionIntegrator(vq, irp)
+                                    : ctype > 0 ? (BilinearFormIntegrator*)new DiffusionIntegrator(*MQs[ctype], irp)
+                                    : (BilinearFormIntegrator*)new DiffusionIntegrator(Q, irp);
       bf.AddDomainIntegrator(bfi);
       bf.Assemble();
       const int N = fes.GetVSize();
@@ -122,6 +165,15 @@ int main(int argc, char **argv)
       diagE = 0.0; bfi->AssembleDiagonalPA(diagE);
       dump("y.f64", y.HostRead(), N); dump("xE.f64", xE.HostRead(), xE.Size()); dump("yE.f64", yE.HostRead(), yE.Size());
       dump("diag.f64", diag.HostRead(), N); dump("diagE.f64", diagE.HostRead(), diagE.Size());
+      if (nonsym)      // no symmetric solve for the full matrix; the operator through the ConstrainedOperator seam
+      {
+         Array<int> none;
+         OperatorPtr A0; bf.FormSystemMatrix(none, A0);
+         Vector cy(N); A0->Mult(x, cy); dump("y_constrained.f64", cy.HostRead(), N);
+         printf("run: non-symmetric D |y|=%.15e\n", y.Norml2());
+         delete mesh;
+         return 0;
+      }
       LinearForm b(&fes);
       b.AddDomainIntegrator(new DomainLFIntegrator(one));
       b.Assemble();

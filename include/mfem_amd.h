@@ -79,10 +79,13 @@ int mfem_amd_geom_jacobians_3d(int Dn, int Q1D, int64_t ne, const double *Bn,
                                void *stream);
 /* GeometricFactors DETERMINANTS (fem/qinterp/det.hpp:209-282): detJ (Q,Q,Q,NE) from J. */
 int mfem_amd_geom_det_3d(int Q1D, int64_t ne, const double *J, double *detJ, void *stream);
-/* PADiffusionSetup3D (fem/integ/bilininteg_diffusion_kernels.cpp:243-367), scalar or
- * vector coefficient (coeffDim 1 or 3): D (Q,Q,Q,6,NE), component order
- * (1,1),(2,1),(3,1),(2,2),(3,2),(3,3).  C: device; const_c != 0 -> C has coeffDim entries,
- * else (coeffDim,Q,Q,Q,NE). */
+/* PADiffusionSetup3D (fem/integ/bilininteg_diffusion_kernels.cpp:243-367).  Scalar or
+ * vector coefficient (coeffDim 1 or 3) and symmetric matrix coefficient (coeffDim 6, entries
+ * (1,1),(1,2),(1,3),(2,2),(2,3),(3,3); :297-348): D (Q,Q,Q,6,NE), component order
+ * (1,1),(2,1),(3,1),(2,2),(3,2),(3,3).  Full matrix coefficient (coeffDim 9, the layout
+ * CoefficientVector::ProjectTranspose leaves, fem/coefficient.cpp:2026-2056): D (Q,Q,Q,9,NE),
+ * row-major planes, `symmetric` = 0 in the apply / diagonal entry points below.
+ * C: device; const_c != 0 -> C has coeffDim entries, else (coeffDim,Q,Q,Q,NE). */
 int mfem_amd_diffusion_setup_3d(int Q1D, int coeffDim, int64_t ne, const double *W,
                                 const double *J, const double *C, int const_c, double *D,
                                 void *stream);
@@ -90,8 +93,8 @@ int mfem_amd_diffusion_setup_3d(int Q1D, int coeffDim, int64_t ne, const double 
 int mfem_amd_mass_setup_3d(int Q1D, int64_t ne, const double *W, const double *detJ,
                            const double *C, int const_c, double *D, void *stream);
 /* Fused nodes -> D: AssemblePA without materialising J (9*Q^3*NE doubles, 1.5x pa_data;
- * SURVEY a-6).  kind 0 = mass (D (Q^3,NE)), 1 = diffusion (D (Q^3,6,NE)); coeffDim 1 or 3
- * (diffusion), 1 (mass).  detJ_out may be NULL; if not, (Q^3,NE) determinants are also
+ * SURVEY a-6).  kind 0 = mass (D (Q^3,NE)), 1 = diffusion (D (Q^3,6,NE), or
+ * (Q^3,9,NE) for coeffDim 9, pa_layout 0 only); coeffDim 1, 3, 6 or 9 (diffusion), 1 (mass).  detJ_out may be NULL; if not, (Q^3,NE) determinants are also
  * written (needed by the RHS).  Same arithmetic per point as the two-step path. */
 int mfem_amd_pa_setup_from_nodes_3d(int kind, int Dn, int Q1D, int coeffDim, int64_t ne,
                                     const double *Bn, const double *Gn, const double *W,
@@ -126,7 +129,9 @@ int mfem_amd_domain_lf_3d(int D1D, int Q1D, int64_t ne, const double *B, const d
  * fallback PADiffusionApply3D (fem/integ/bilininteg_diffusion_pa.cpp:40-74,
  * fem/integ/bilininteg_diffusion_kernels.hpp:988-1211, 795-985).  Signature mirrors
  * DiffusionIntegrator::ApplyKernelType (fem/bilininteg.hpp:2181-2185):
- * yE += G^T D G xE per element.  Only symmetric != 0 (6-component D) is supported. */
+ * yE += G^T D G xE per element.  symmetric != 0: 6-plane D, the specialised kernels;
+ * symmetric == 0: the 9-plane D of a full matrix coefficient (bilininteg_diffusion_kernels.hpp:
+ * 1119-1127), which runs through the runtime-(D,Q) LDS kernel for every order. */
 int mfem_amd_pa_diffusion_apply_3d(int D1D, int Q1D, int64_t ne, int symmetric,
                                    const double *B, const double *G, const double *D,
                                    const double *xE, double *yE, void *stream);
@@ -137,7 +142,8 @@ int mfem_amd_pa_mass_apply_3d(int D1D, int Q1D, int64_t ne, const double *B,
                               const double *D, const double *xE, double *yE, void *stream);
 /* AssembleDiagonalPA: SmemPADiffusionDiagonal3D / SmemPAMassAssembleDiagonal3D
  * (fem/integ/bilininteg_diffusion_kernels.hpp:368-484, bilininteg_mass_kernels.hpp:324-408;
- * DiagonalKernelType fem/bilininteg.hpp:2187-2189).  diagE += diag(A_e). */
+ * DiagonalKernelType fem/bilininteg.hpp:2187-2189).  diagE += diag(A_e).  symmetric == 0:
+ * 9-plane D, k = 3 i + j (:428-431), pa_layout 0 only. */
 int mfem_amd_pa_diffusion_diag_3d(int D1D, int Q1D, int64_t ne, int symmetric,
                                   const double *B, const double *G, const double *D,
                                   int pa_layout, double *diagE, void *stream);
@@ -147,7 +153,8 @@ int mfem_amd_pa_mass_diag_3d(int D1D, int Q1D, int64_t ne, const double *B,
 /* PABilinearFormExtension::MultInternal, H1 branch, one integrator
  * (fem/bilinearform_ext.cpp:487-564): yE = A_E (gather x) with the L->E gather fused into
  * the element kernel (no localX round trip, no memset of localY).  kind 0 mass / 1
- * diffusion.  gather_map entries < 0 here mean "use 0.0" (masked essential dofs, see
+ * diffusion / 2 diffusion with the non-symmetric 9-plane D (pa_layout 0 only; the operator
+ * struct below takes the same kinds).  gather_map entries < 0 here mean "use 0.0" (masked essential dofs, see
  * mfem_amd_mask_gather_map) -- scalar H1 gather maps are never negative in the reference.
  * Follow with mfem_amd_restrict_scatter[_dot] for the E->L sum. */
 int mfem_amd_pa_apply_L2E(int kind, int pa_layout, int D1D, int Q1D, int64_t ne,

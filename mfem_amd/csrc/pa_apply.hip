@@ -736,7 +736,8 @@ k_pa_apply_generic(const int D, const int Q, const int64_t ne, const BasisT<MAX_
                    const double *__restrict__ Dq, const double *__restrict__ x,
                    const int *__restrict__ gmap, double *__restrict__ yE, const VecArgs va, const int comp)
 {
-   constexpr int NC = KIND ? 6 : 1, NF = KIND ? 3 : 1, NX = KIND ? 2 : 1;
+   // KIND 2: diffusion with the full 3x3 D of a non-symmetric matrix coefficient (9 planes, row-major)
+   constexpr int NC = KIND == 2 ? 9 : (KIND ? 6 : 1), NF = KIND ? 3 : 1, NX = KIND ? 2 : 1;
    extern __shared__ __align__(16) double dyn[];
    const int D3 = D*D*D, DDQ = D*D*Q, DQQ = D*Q*Q, Q3 = Q*Q*Q, QQ = Q*Q;
    double *sB = dyn, *sG = sB + Q*D;
@@ -815,10 +816,15 @@ k_pa_apply_generic(const int D, const int Q, const int64_t ne, const BasisT<MAX_
             gY += bz*s2[DQQ + dz*QQ + qq];
             gZ += gz*s2[dz*QQ + qq];
          }
+         // plane order of the reference (bilininteg_diffusion_kernels.hpp:1119-1127)
          const double O11 = De[0], O12 = De[Q3], O13 = De[2*(int64_t)Q3];
-         const double O22 = De[3*(int64_t)Q3], O23 = De[4*(int64_t)Q3], O33 = De[5*(int64_t)Q3];
-         s3[i] = (O13*gX) + (O23*gY) + (O33*gZ);
-         s3[Q3 + i] = (O12*gX) + (O22*gY) + (O23*gZ);
+         const double O21 = KIND == 2 ? De[3*(int64_t)Q3] : O12;
+         const double O22 = De[(KIND == 2 ? 4 : 3)*(int64_t)Q3], O23 = De[(KIND == 2 ? 5 : 4)*(int64_t)Q3];
+         const double O31 = KIND == 2 ? De[6*(int64_t)Q3] : O13;
+         const double O32 = KIND == 2 ? De[7*(int64_t)Q3] : O23;
+         const double O33 = De[(KIND == 2 ? 8 : 5)*(int64_t)Q3];
+         s3[i] = (O31*gX) + (O32*gY) + (O33*gZ);
+         s3[Q3 + i] = (O21*gX) + (O22*gY) + (O23*gZ);
          s3[2*Q3 + i] = (O11*gX) + (O12*gY) + (O13*gZ);
       }
       else
@@ -1063,6 +1069,34 @@ static int run_apply(int D, int Q, int64_t ne, const double *B, const double *G,
    return 0;
 }
 
+// Non-symmetric D (matrix coefficient, 9 planes): the reference has no specialisation of its own for
+// it either (one kernel, `symmetric` a runtime flag); here it runs through the LDS fallback kernel.
+template <bool GATHER, bool ACCUM>
+static int run_apply_nonsym(int D, int Q, int64_t ne, const double *B, const double *G,
+                            const double *Dq, const double *x, const int *gmap, double *yE,
+                            hipStream_t s)
+{
+   MFA_REQUIRE(D >= 2 && D <= MAX_D1D && Q >= 1 && Q <= MAX_Q1D && D*Q <= MAX_DQ,
+               "pa_apply: unsupported (D1D,Q1D) = (%d,%d); limits D1D<=%d, Q1D<=%d, D1D*Q1D<=%d",
+               D, Q, MAX_D1D, MAX_Q1D, MAX_DQ);
+   MFA_REQUIRE(B && G && Dq && x && yE && (!GATHER || gmap), "pa_apply: null pointer argument");
+   if (ne == 0) { return 0; }
+   MFA_REQUIRE(ne < (int64_t)2147483647, "pa_apply: too many elements for the fallback kernel");
+   BasisT<MAX_DQ> bg;
+   fill_basis(bg, D, Q, B, G);
+   const size_t lds = sizeof(double)*(size_t)(2*Q*D + D*D*D + 2*D*D*Q + 3*D*Q*Q + 3*Q*Q*Q);
+   MFA_REQUIRE(lds <= 160*1024, "pa_apply: fallback kernel needs %zu B of LDS (> 160 KiB)", lds);
+   auto kern = k_pa_apply_generic<2, GATHER, ACCUM>;
+   if (lds > 64*1024)
+   {
+      if (int rc = check_hip(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                             "hipFuncSetAttribute")) { return rc; }
+   }
+   kern<<<dim3((unsigned)ne), dim3(256), lds, s>>>(D, Q, ne, bg, Dq, x, gmap, yE, VecArgs{}, 0);
+   MFA_CHECK_LAUNCH("k_pa_apply_generic (non-symmetric D)");
+   return 0;
+}
+
 
 // ---- vector spaces: one launch, the workgroup loops over the components -------------------
 typedef int (*apply_vec_fn)(int64_t ne, const double *B, const double *G, const double *Dq,
@@ -1134,6 +1168,7 @@ static int run_apply_vec(int D, int Q, int64_t ne, const double *B, const double
 int pa_apply_L2E_vec(int kind, int layout, int D, int Q, int64_t ne, const double *B, const double *G,
                      const double *Dq, const int *gmap, const double *x, double *yE, VecArgs va, hipStream_t s)
 {
+   MFA_REQUIRE(kind == 0 || kind == 1, "pa_apply (vector space): kind must be 0 (mass) or 1 (diffusion)");
    if (layout)
    {
       if (kind == 0) { return run_apply_vec<0, true, false, true>(D, Q, ne, B, G, Dq, x, gmap, yE, va, s); }
@@ -1146,6 +1181,11 @@ int pa_apply_L2E_vec(int kind, int layout, int D, int Q, int64_t ne, const doubl
 int pa_apply_L2E(int kind, int layout, int D, int Q, int64_t ne, const double *B, const double *G,
                  const double *Dq, const int *gmap, const double *x, double *yE, hipStream_t s)
 {
+   if (kind == 2)
+   {
+      MFA_REQUIRE(layout == 0, "pa_apply: the non-symmetric D (kind 2) has the MFEM layout only");
+      return run_apply_nonsym<true, false>(D, Q, ne, B, G, Dq, x, gmap, yE, s);
+   }
    if (layout)
    {
       if (kind == 0) { return run_apply<0, true, false, true>(D, Q, ne, B, G, Dq, x, gmap, yE, s); }
@@ -1170,7 +1210,7 @@ extern "C" int mfem_amd_pa_diffusion_apply_3d(int D1D, int Q1D, int64_t ne, int 
                                               const double *D, const double *xE, double *yE,
                                               void *stream)
 {
-   MFA_REQUIRE(symmetric, "pa_diffusion_apply_3d: only the symmetric (6-component) D is supported");
+   if (!symmetric) { return run_apply_nonsym<false, true>(D1D, Q1D, ne, B, G, D, xE, nullptr, yE, as_stream(stream)); }
    return run_apply<1, false, true, false>(D1D, Q1D, ne, B, G, D, xE, nullptr, yE, as_stream(stream));
 }
 
@@ -1186,7 +1226,7 @@ extern "C" int mfem_amd_pa_apply_L2E(int kind, int pa_layout, int D1D, int Q1D, 
                                      const int *gather_map, const double *x, double *yE,
                                      void *stream)
 {
-   MFA_REQUIRE(kind == 0 || kind == 1, "pa_apply_L2E: kind must be 0 (mass) or 1 (diffusion)");
+   MFA_REQUIRE(kind >= 0 && kind <= 2, "pa_apply_L2E: kind must be 0 (mass), 1 (diffusion) or 2 (diffusion, non-symmetric D)");
    MFA_REQUIRE(pa_layout == 0 || pa_layout == 1, "pa_apply_L2E: pa_layout must be 0 (MFEM) or 1 (blocked)");
    return pa_apply_L2E(kind, pa_layout, D1D, Q1D, ne, B, G, D, gather_map, x, yE, as_stream(stream));
 }
@@ -1239,6 +1279,7 @@ extern "C" int mfem_amd_pa_vector_mass_apply_3d(int D1D, int Q1D, int64_t ne, in
 
 extern "C" int64_t mfem_amd_pa_data_size(int kind, int pa_layout, int Q1D, int64_t ne)
 {
+   if (kind == 2) { return pa_layout ? -1 : ne*(int64_t)9*Q1D*Q1D*Q1D; }
    if (pa_layout) { return blocked_size(kind, Q1D, ne); }
    return ne*(int64_t)(kind ? 6 : 1)*Q1D*Q1D*Q1D;
 }

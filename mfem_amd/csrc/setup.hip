@@ -132,6 +132,61 @@ __device__ __forceinline__ void diffusion_point(const double J11, const double J
    out[5] = w_detJ*(C1*A31*A31 + C2*A32*A32 + C3*A33*A33);
 }
 
+// Matrix coefficient (PADiffusionSetup3D, bilininteg_diffusion_kernels.cpp:297-348): c holds the
+// 6 entries (1,1),(1,2),(1,3),(2,2),(2,3),(3,3) of a symmetric M, or the 9 of a full M as the
+// reference's ProjectTranspose stores them; D = (W/detJ) adj(J) M adj(J)^T with the reference's
+// grouping (R = M adj(J)^T first).  out: 6 planes (symmetric) or 9 row-major planes.
+__device__ __forceinline__ void diffusion_point_matrix(const double J11, const double J21, const double J31,
+                                                       const double J12, const double J22, const double J32,
+                                                       const double J13, const double J23, const double J33,
+                                                       const double W, const double *c, const bool symmetric,
+                                                       double *out, double &detJ)
+{
+   detJ = J11*(J22*J33 - J32*J23) - J21*(J12*J33 - J32*J13) + J31*(J12*J23 - J22*J13);
+   const double w_detJ = W/detJ;
+   const double A11 = (J22*J33) - (J23*J32);
+   const double A12 = (J32*J13) - (J12*J33);
+   const double A13 = (J12*J23) - (J22*J13);
+   const double A21 = (J31*J23) - (J21*J33);
+   const double A22 = (J11*J33) - (J13*J31);
+   const double A23 = (J21*J13) - (J11*J23);
+   const double A31 = (J21*J32) - (J31*J22);
+   const double A32 = (J31*J12) - (J11*J32);
+   const double A33 = (J11*J22) - (J12*J21);
+   const double M11 = c[0], M12 = c[1], M13 = c[2];
+   const double M21 = symmetric ? M12 : c[3];
+   const double M22 = symmetric ? c[3] : c[4];
+   const double M23 = symmetric ? c[4] : c[5];
+   const double M31 = symmetric ? M13 : c[6];
+   const double M32 = symmetric ? M23 : c[7];
+   const double M33 = symmetric ? c[5] : c[8];
+   const double R11 = M11*A11 + M12*A12 + M13*A13;
+   const double R12 = M11*A21 + M12*A22 + M13*A23;
+   const double R13 = M11*A31 + M12*A32 + M13*A33;
+   const double R21 = M21*A11 + M22*A12 + M23*A13;
+   const double R22 = M21*A21 + M22*A22 + M23*A23;
+   const double R23 = M21*A31 + M22*A32 + M23*A33;
+   const double R31 = M31*A11 + M32*A12 + M33*A13;
+   const double R32 = M31*A21 + M32*A22 + M33*A23;
+   const double R33 = M31*A31 + M32*A32 + M33*A33;
+   const double D11 = w_detJ*(A11*R11 + A12*R21 + A13*R31);
+   const double D12 = w_detJ*(A11*R12 + A12*R22 + A13*R32);
+   const double D13 = w_detJ*(A11*R13 + A12*R23 + A13*R33);
+   const double D22 = w_detJ*(A21*R12 + A22*R22 + A23*R32);
+   const double D23 = w_detJ*(A21*R13 + A22*R23 + A23*R33);
+   const double D33 = w_detJ*(A31*R13 + A32*R23 + A33*R33);
+   out[0] = D11; out[1] = D12; out[2] = D13;
+   if (symmetric) { out[3] = D22; out[4] = D23; out[5] = D33; }
+   else
+   {
+      out[3] = w_detJ*(A21*R11 + A22*R21 + A23*R31);
+      out[4] = D22; out[5] = D23;
+      out[6] = w_detJ*(A31*R11 + A32*R21 + A33*R31);
+      out[7] = w_detJ*(A31*R12 + A32*R22 + A33*R32);
+      out[8] = D33;
+   }
+}
+
 // kind 0: mass, 1: diffusion.  One workgroup per element.
 __global__ void __launch_bounds__(256)
 k_setup_from_nodes(const int kind, const int Dn, const int Q, const int coeffDim,
@@ -151,12 +206,20 @@ k_setup_from_nodes(const int kind, const int Dn, const int Q, const int coeffDim
       const double J21 = sJ[3*Q3 + q], J22 = sJ[4*Q3 + q], J23 = sJ[5*Q3 + q];
       const double J31 = sJ[6*Q3 + q], J32 = sJ[7*Q3 + q], J33 = sJ[8*Q3 + q];
       const double *c = const_c ? C : C + coeffDim*(q + (int64_t)Q3*e);
-      double out[6], detJ;
+      double out[9], detJ;
       if (kind)
       {
-         const double C1 = c[0], C2 = c[coeffDim == 3 ? 1 : 0], C3 = c[coeffDim == 3 ? 2 : 0];
-         diffusion_point(J11, J21, J31, J12, J22, J32, J13, J23, J33, W[q], C1, C2, C3, out, detJ);
-         for (int k = 0; k < 6; k++) { D[layout ? blocked_index(1, Q, e, q, k) : q + (int64_t)Q3*(k + 6*e)] = out[k]; }
+         const int nc = coeffDim == 9 ? 9 : 6;
+         if (coeffDim >= 6)
+         {
+            diffusion_point_matrix(J11, J21, J31, J12, J22, J32, J13, J23, J33, W[q], c, coeffDim == 6, out, detJ);
+         }
+         else
+         {
+            const double C1 = c[0], C2 = c[coeffDim == 3 ? 1 : 0], C3 = c[coeffDim == 3 ? 2 : 0];
+            diffusion_point(J11, J21, J31, J12, J22, J32, J13, J23, J33, W[q], C1, C2, C3, out, detJ);
+         }
+         for (int k = 0; k < nc; k++) { D[layout ? blocked_index(1, Q, e, q, k) : q + (int64_t)Q3*(k + nc*e)] = out[k]; }
       }
       else
       {
@@ -259,10 +322,18 @@ k_diffusion_setup(const int64_t n, const int Q3, const int coeffDim,
    const double J12 = Je[3*(int64_t)Q3], J22 = Je[4*(int64_t)Q3], J32 = Je[5*(int64_t)Q3];
    const double J13 = Je[6*(int64_t)Q3], J23 = Je[7*(int64_t)Q3], J33 = Je[8*(int64_t)Q3];
    const double *c = const_c ? C : C + coeffDim*i;
-   const double C1 = c[0], C2 = c[coeffDim == 3 ? 1 : 0], C3 = c[coeffDim == 3 ? 2 : 0];
-   double out[6], detJ;
-   diffusion_point(J11, J21, J31, J12, J22, J32, J13, J23, J33, W[q], C1, C2, C3, out, detJ);
-   for (int k = 0; k < 6; k++) { D[q + (int64_t)Q3*(k + 6*e)] = out[k]; }
+   double out[9], detJ;
+   const int nc = coeffDim == 9 ? 9 : 6;
+   if (coeffDim >= 6)
+   {
+      diffusion_point_matrix(J11, J21, J31, J12, J22, J32, J13, J23, J33, W[q], c, coeffDim == 6, out, detJ);
+   }
+   else
+   {
+      const double C1 = c[0], C2 = c[coeffDim == 3 ? 1 : 0], C3 = c[coeffDim == 3 ? 2 : 0];
+      diffusion_point(J11, J21, J31, J12, J22, J32, J13, J23, J33, W[q], C1, C2, C3, out, detJ);
+   }
+   for (int k = 0; k < nc; k++) { D[q + (int64_t)Q3*(k + nc*e)] = out[k]; }
 }
 
 __global__ void __launch_bounds__(256)
@@ -281,7 +352,7 @@ k_mass_setup(const int64_t n, const int Q3, const double *__restrict__ W,
 template <int KIND>
 __global__ void __launch_bounds__(256)
 k_diag(const int D, const int Q, const BasisT<MAX_DQ> bg, const double *__restrict__ Dq,
-       double *__restrict__ Y, const int layout)
+       double *__restrict__ Y, const int layout, const int nonsym)
 {
    extern __shared__ __align__(16) double dyn[];
    const int Q3 = Q*Q*Q, QQ = Q*Q, D3 = D*D*D;
@@ -294,8 +365,10 @@ k_diag(const int D, const int Q, const BasisT<MAX_DQ> bg, const double *__restri
    for (int pass = 0; pass < npass; pass++)
    {
       const int ii = pass/3, jj = pass % 3;
-      const int k = KIND ? (jj >= ii ? 3 - (3 - ii)*(2 - ii)/2 + jj : 3 - (3 - jj)*(2 - jj)/2 + ii) : 0;
-      const double *De = Dq + (int64_t)Q3*(k + (KIND ? 6 : 1)*e);   // layout 0
+      // symmetric: the reference's ksym map; full D: k = 3 i + j (bilininteg_diffusion_kernels.hpp:428-431)
+      const int ksym = KIND ? (jj >= ii ? 3 - (3 - ii)*(2 - ii)/2 + jj : 3 - (3 - jj)*(2 - jj)/2 + ii) : 0;
+      const int k = nonsym ? 3*ii + jj : ksym;
+      const double *De = Dq + (int64_t)Q3*(k + (KIND ? (nonsym ? 9 : 6) : 1)*e);   // layout 0
       for (int i = tid; i < QQ*D; i += nt)        // [qx][qy][dz]
       {
          const int dz = i % D, qy = (i/D) % Q, qx = i/(D*Q);
@@ -404,8 +477,8 @@ extern "C" int mfem_amd_diffusion_setup_3d(int Q1D, int coeffDim, int64_t ne, co
    const int64_t n = ne*Q1D*Q1D*Q1D;
    if (n == 0) { return 0; }
    MFA_REQUIRE(Q1D >= 1 && Q1D <= MAX_Q1D, "diffusion_setup_3d: Q1D = %d out of range", Q1D);
-   MFA_REQUIRE(coeffDim == 1 || coeffDim == 3,
-               "diffusion_setup_3d: coeffDim = %d (matrix coefficients are not supported)", coeffDim);
+   MFA_REQUIRE(coeffDim == 1 || coeffDim == 3 || coeffDim == 6 || coeffDim == 9,
+               "diffusion_setup_3d: coeffDim = %d (1 scalar, 3 vector, 6 symmetric matrix, 9 matrix)", coeffDim);
    MFA_REQUIRE(n > 0 && W && J && C && D, "diffusion_setup_3d: bad arguments");
    const double *dW = W;
    k_diffusion_setup<<<dim3((unsigned)((n + 255)/256)), dim3(256), 0, as_stream(stream)>>>(
@@ -437,7 +510,9 @@ extern "C" int mfem_amd_pa_setup_from_nodes_3d(int kind, int Dn, int Q1D, int co
    if (ne == 0) { return 0; }
    MFA_REQUIRE(kind == 0 || kind == 1, "pa_setup_from_nodes_3d: kind must be 0 or 1");
    MFA_REQUIRE(pa_layout == 0 || pa_layout == 1, "pa_setup_from_nodes_3d: pa_layout must be 0 or 1");
-   MFA_REQUIRE(coeffDim == 1 || (kind == 1 && coeffDim == 3), "pa_setup_from_nodes_3d: coeffDim = %d unsupported", coeffDim);
+   MFA_REQUIRE(coeffDim == 1 || (kind == 1 && (coeffDim == 3 || coeffDim == 6 || coeffDim == 9)),
+               "pa_setup_from_nodes_3d: coeffDim = %d unsupported", coeffDim);
+   MFA_REQUIRE(!(coeffDim == 9 && pa_layout), "pa_setup_from_nodes_3d: the 9-plane D of a full matrix coefficient has the MFEM layout only");
    MFA_REQUIRE(ne > 0 && ne < 2147483647 && W && nodesE && C && D && Gn, "pa_setup_from_nodes_3d: bad arguments");
    BasisT<MAX_DQ> bg;
    if (int rc = fill_basis_dyn(bg, Dn, Q1D, Bn, Gn)) { return rc; }
@@ -494,13 +569,13 @@ extern "C" int mfem_amd_pa_diffusion_diag_3d(int D1D, int Q1D, int64_t ne, int s
 {
    if (ne == 0) { return 0; }
    MFA_REQUIRE(pa_layout == 0 || pa_layout == 1, "pa_diffusion_diag_3d: pa_layout must be 0 or 1");
-   MFA_REQUIRE(symmetric, "pa_diffusion_diag_3d: only the symmetric (6-component) D is supported");
+   MFA_REQUIRE(symmetric || pa_layout == 0, "pa_diffusion_diag_3d: the non-symmetric (9-plane) D has the MFEM layout only");
    MFA_REQUIRE(ne > 0 && ne < 2147483647 && D && diagE && G, "pa_diffusion_diag_3d: bad arguments");
    BasisT<MAX_DQ> bg;
    if (int rc = fill_basis_dyn(bg, D1D, Q1D, B, G)) { return rc; }
    const size_t lds = sizeof(double)*(size_t)(2*Q1D*D1D + Q1D*Q1D*D1D + Q1D*D1D*D1D);
    if (int rc = set_lds(k_diag<1>, lds)) { return rc; }
-   k_diag<1><<<dim3((unsigned)ne), dim3(256), lds, as_stream(stream)>>>(D1D, Q1D, bg, D, diagE, pa_layout);
+   k_diag<1><<<dim3((unsigned)ne), dim3(256), lds, as_stream(stream)>>>(D1D, Q1D, bg, D, diagE, pa_layout, symmetric ? 0 : 1);
    MFA_CHECK_LAUNCH("k_diag<diffusion>");
    return 0;
 }
@@ -516,7 +591,7 @@ extern "C" int mfem_amd_pa_mass_diag_3d(int D1D, int Q1D, int64_t ne, const doub
    if (int rc = fill_basis_dyn(bg, D1D, Q1D, B, nullptr)) { return rc; }
    const size_t lds = sizeof(double)*(size_t)(2*Q1D*D1D + Q1D*Q1D*D1D + Q1D*D1D*D1D);
    if (int rc = set_lds(k_diag<0>, lds)) { return rc; }
-   k_diag<0><<<dim3((unsigned)ne), dim3(256), lds, as_stream(stream)>>>(D1D, Q1D, bg, D, diagE, pa_layout);
+   k_diag<0><<<dim3((unsigned)ne), dim3(256), lds, as_stream(stream)>>>(D1D, Q1D, bg, D, diagE, pa_layout, 0);
    MFA_CHECK_LAUNCH("k_diag<mass>");
    return 0;
 }

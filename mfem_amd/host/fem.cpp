@@ -397,10 +397,28 @@ void prepare_nodes(Mesh &mesh, const IntegrationRule &ir, NodesAtRule &g)
 }
 // CoefficientVector::Project (fem/coefficient.cpp:1985-2051): a constant stays one number,
 // anything else is evaluated at the physical quadrature points, (Q^3, NE).
-void eval_coefficient(Mesh &mesh, const IntegrationRule &ir, Coefficient *Q, Vector &C, int &const_c)
+// With VQ or MQ: coeffDim = 3, 6 (symmetric matrix) or 9 entries per point, (coeffDim, Q^3, NE), or
+// coeffDim numbers for the constant classes (CoefficientStorage::COMPRESSED).
+void eval_coefficient(Mesh &mesh, const IntegrationRule &ir, Coefficient *Q, Vector &C, int &const_c,
+                      VectorCoefficient *VQ = nullptr, MatrixCoefficient *MQ = nullptr, int *coeffDim = nullptr)
 {
+   const int cd = MQ ? MQ->PackedSize() : (VQ ? VQ->GetVDim() : 1);
+   if (coeffDim) { *coeffDim = cd; }
+   if (MQ || VQ) { MFEM_VERIFY(MQ ? MQ->GetHeight() == 3 && MQ->GetWidth() == 3 : cd == 3, "mfem_amd: vector / matrix coefficients of dimension 3"); }
+   Vector cvec;
+   if (MQ && MQ->IsConstant())
+   {
+      Vector origin(3); origin = 0.0;
+      C.SetSize(cd); MQ->PackedAt(origin, C.HostWrite()); const_c = 1;
+      return;
+   }
+   if (!MQ && VQ && VQ->IsConstant(cvec))
+   {
+      C.SetSize(cd); for (int k = 0; k < cd; k++) { C.HostWrite()[k] = cvec(k); } const_c = 1;
+      return;
+   }
    real_t cval = 1.0;
-   if (!Q || Q->IsConstant(cval))
+   if (!MQ && !VQ && (!Q || Q->IsConstant(cval)))
    {
       C.SetSize(1); C.HostWrite()[0] = cval; const_c = 1;
       return;
@@ -413,16 +431,19 @@ void eval_coefficient(Mesh &mesh, const IntegrationRule &ir, Coefficient *Q, Vec
    const int Q1 = ir.n1d, nq = Q1*Q1*Q1, ndn = Dn*Dn*Dn, NE = mesh.GetNE();
    const std::vector<real_t> P = internal::InterpMatrix(gn, ir.x1d);
    std::vector<real_t> loc((size_t)3*nq);
-   C.SetSize(nq*NE);
+   C.SetSize(cd*nq*NE);
    real_t *c = C.HostWrite();
-   Vector pt(3);
+   Vector pt(3), v(3);
    for (int e = 0; e < NE; e++)
    {
       internal::TensorInterp3(Dn, Q1, P.data(), P.data(), P.data(), &xe[(size_t)3*ndn*e], loc.data());
       for (int q = 0; q < nq; q++)
       {
          for (int k = 0; k < 3; k++) { pt(k) = loc[q + nq*k]; }
-         c[(size_t)nq*e + q] = Q->EvalAt(pt);
+         real_t *cq = c + (size_t)cd*((size_t)nq*e + q);
+         if (MQ) { MQ->PackedAt(pt, cq); }
+         else if (VQ) { VQ->EvalAt(pt, v); for (int k = 0; k < cd; k++) { cq[k] = v(k); } }
+         else { cq[0] = Q->EvalAt(pt); }
       }
    }
 }
@@ -488,7 +509,8 @@ const IntegrationRule &MassIntegrator::GetRule(const FiniteElement &trial_fe, co
 
 // AssemblePA (fem/integ/bilininteg_diffusion_pa.cpp:89-147, bilininteg_mass_pa.cpp:24-79) with
 // the geometric factors fused in: nodes -> pa_data in one kernel, J is never stored.
-void BilinearFormIntegrator::SetupPA(const FiniteElementSpace &fes, int kind_, Coefficient *Q, const IntegrationRule &ir)
+void BilinearFormIntegrator::SetupPA(const FiniteElementSpace &fes, int kind_, Coefficient *Q, const IntegrationRule &ir,
+                                     VectorCoefficient *VQ, MatrixCoefficient *MQ)
 {
    MFEM_VERIFY(vector_integrator || fes.GetVDim() == 1, "mfem_amd: a scalar integrator needs a scalar space (use the Vector* integrators)");
    vdim = fes.GetVDim();
@@ -498,14 +520,16 @@ void BilinearFormIntegrator::SetupPA(const FiniteElementSpace &fes, int kind_, C
    maps = &fe->GetDofToQuad(ir, DofToQuad::TENSOR);
    dofs1D = maps->ndof; quad1D = maps->nqpt;
    // the blocked HBM layout needs a specialised (D1D,Q1D) kernel; otherwise keep MFEM's layout
-   pa_layout = mfem_amd_has_specialization(kind, dofs1D, quad1D) ? 1 : 0;
    pa_data_mfem.Destroy();
    NodesAtRule g; prepare_nodes(*mesh, ir, g);
-   Vector C; int const_c;
-   eval_coefficient(*mesh, ir, Q, C, const_c);
-   pa_data.SetSize((int)mfem_amd_pa_data_size(kind, pa_layout, quad1D, ne));
+   Vector C; int const_c, coeffDim = 1;
+   eval_coefficient(*mesh, ir, Q, C, const_c, VQ, MQ, &coeffDim);
+   // symmetric = (coeff_dim != dims*dims), fem/integ/bilininteg_diffusion_pa.cpp:135-137
+   symmetric = coeffDim != 9;
+   pa_layout = (symmetric && mfem_amd_has_specialization(kind, dofs1D, quad1D)) ? 1 : 0;
+   pa_data.SetSize((int)mfem_amd_pa_data_size(OperatorKind(), pa_layout, quad1D, ne));
    if (pa_layout) { pa_data.Write(); pa_data = 0.0; }     // padding of the last batch must be finite
-   MFEM_AMD_CALL(mfem_amd_pa_setup_from_nodes_3d(kind, g.Dn, quad1D, 1, ne, g.Bn.data(), g.Gn.data(), ir.GetWeights().Read(),
+   MFEM_AMD_CALL(mfem_amd_pa_setup_from_nodes_3d(kind, g.Dn, quad1D, coeffDim, ne, g.Bn.data(), g.Gn.data(), ir.GetWeights().Read(),
                                                  g.nodesE.Read(), C.Read(), const_c, pa_layout,
                                                  pa_layout ? pa_data.ReadWrite() : pa_data.Write(), nullptr, nullptr));
 }
@@ -522,18 +546,23 @@ const Vector &BilinearFormIntegrator::MFEMLayoutData() const
 void DiffusionIntegrator::AssemblePA(const FiniteElementSpace &fes)
 {
    const FiniteElement &el = *fes.GetTypicalFE();
-   SetupPA(fes, 1, Q, IntRule ? *IntRule : GetRule(el, el));
+   SetupPA(fes, 1, Q, IntRule ? *IntRule : GetRule(el, el), VQ, MQ);
 }
 void DiffusionIntegrator::AddMultPA(const Vector &x, Vector &y) const
 {
    MFEM_VERIFY(maps, "AssemblePA must be called first");
-   MFEM_AMD_CALL(mfem_amd_pa_diffusion_apply_3d(dofs1D, quad1D, ne, 1, maps->B.HostRead(), maps->G.HostRead(),
+   MFEM_AMD_CALL(mfem_amd_pa_diffusion_apply_3d(dofs1D, quad1D, ne, symmetric ? 1 : 0, maps->B.HostRead(), maps->G.HostRead(),
                                                 MFEMLayoutData().Read(), x.Read(), y.ReadWrite(), nullptr));
+}
+void DiffusionIntegrator::AddMultTransposePA(const Vector &x, Vector &y) const
+{
+   MFEM_VERIFY(symmetric, "DiffusionIntegrator::AddMultTransposePA only implemented in the symmetric case.");
+   AddMultPA(x, y);
 }
 void DiffusionIntegrator::AssembleDiagonalPA(Vector &diag)
 {
    MFEM_VERIFY(maps, "AssemblePA must be called first");
-   MFEM_AMD_CALL(mfem_amd_pa_diffusion_diag_3d(dofs1D, quad1D, ne, 1, maps->B.HostRead(), maps->G.HostRead(),
+   MFEM_AMD_CALL(mfem_amd_pa_diffusion_diag_3d(dofs1D, quad1D, ne, symmetric ? 1 : 0, maps->B.HostRead(), maps->G.HostRead(),
                                                pa_data.Read(), pa_layout, diag.ReadWrite(), nullptr));
 }
 void MassIntegrator::AssemblePA(const FiniteElementSpace &fes)
@@ -619,7 +648,7 @@ void PABilinearFormExtension::Mult(const Vector &x, Vector &y) const
    else if (const BilinearFormIntegrator *bfi = SingleIntegrator())
    {
       // gather fused into the element kernel: no localX, no memset of localY
-      MFEM_AMD_CALL(mfem_amd_pa_apply_L2E(bfi->kind, bfi->pa_layout, bfi->dofs1D, bfi->quad1D, bfi->ne,
+      MFEM_AMD_CALL(mfem_amd_pa_apply_L2E(bfi->OperatorKind(), bfi->pa_layout, bfi->dofs1D, bfi->quad1D, bfi->ne,
                                           bfi->maps->B.HostRead(), bfi->maps->G.HostRead(), bfi->pa_data.Read(),
                                           elem_restrict->GatherMap().Read(), x.Read(), localY.Write(), nullptr));
    }
@@ -728,7 +757,7 @@ bool PABilinearFormExtension::FillOperator(mfem_amd_pa_operator &op) const
    if (!bfi || !elem_restrict) { return false; }
    std::memset(&op, 0, sizeof(op));
    const ElementRestriction *R = elem_restrict;
-   op.kind = bfi->kind; op.pa_layout = bfi->pa_layout; op.D1D = bfi->dofs1D; op.Q1D = bfi->quad1D;
+   op.kind = bfi->OperatorKind(); op.pa_layout = bfi->pa_layout; op.D1D = bfi->dofs1D; op.Q1D = bfi->quad1D;
    op.ne = bfi->ne; op.ndofs = fes->GetNDofs();
    if (fes->GetVDim() > 1)
    {

@@ -506,6 +506,8 @@ public:
    virtual ~VectorCoefficient() {}
    int GetVDim() const { return vdim; }
    virtual bool IsConstant(Vector &) const { return false; }
+   /// value at a physical point
+   virtual void EvalAt(const Vector &x, Vector &v) const { Vector c; MFEM_VERIFY(IsConstant(c), "VectorCoefficient::EvalAt is not implemented"); v = c; (void)x; }
 };
 class VectorConstantCoefficient : public VectorCoefficient
 {
@@ -521,6 +523,121 @@ class FunctionCoefficient : public Coefficient
 public:
    explicit FunctionCoefficient(std::function<real_t(const Vector &)> f) : F(std::move(f)) {}
    real_t EvalAt(const Vector &x) const override { return F(x); }
+};
+class VectorFunctionCoefficient : public VectorCoefficient
+{
+   std::function<void(const Vector &, Vector &)> F;
+public:
+   VectorFunctionCoefficient(int dim, std::function<void(const Vector &, Vector &)> f) : VectorCoefficient(dim), F(std::move(f)) {}
+   void EvalAt(const Vector &x, Vector &v) const override { v.SetSize(vdim); F(x, v); }
+};
+/// linalg/densemat.hpp, the little of it the matrix coefficients need: small column-major matrix on the host
+class DenseMatrix
+{
+   int h = 0, w = 0; std::vector<real_t> a;
+public:
+   DenseMatrix() {}
+   explicit DenseMatrix(int n) { SetSize(n); }
+   DenseMatrix(int m, int n) { SetSize(m, n); }
+   void SetSize(int n) { SetSize(n, n); }
+   void SetSize(int m, int n) { h = m; w = n; a.assign((size_t)m*n, 0.0); }
+   int Height() const { return h; }
+   int Width() const { return w; }
+   real_t &operator()(int i, int j) { return a[i + (size_t)h*j]; }
+   const real_t &operator()(int i, int j) const { return a[i + (size_t)h*j]; }
+   DenseMatrix &operator=(real_t v) { for (auto &t : a) { t = v; } return *this; }
+};
+/// linalg/symmat.hpp: upper triangle stored row by row, (0,0),(0,1),...,(1,1),...
+class DenseSymmetricMatrix
+{
+   int n = 0; std::vector<real_t> a;
+   int idx(int i, int j) const { if (i > j) { std::swap(i, j); } return i*n - i*(i - 1)/2 + (j - i); }
+public:
+   DenseSymmetricMatrix() {}
+   explicit DenseSymmetricMatrix(int s) { SetSize(s); }
+   void SetSize(int s) { n = s; a.assign((size_t)s*(s + 1)/2, 0.0); }
+   int Height() const { return n; }
+   int Width() const { return n; }
+   real_t &operator()(int i, int j) { return a[idx(i, j)]; }
+   const real_t &operator()(int i, int j) const { return a[idx(i, j)]; }
+   const real_t *GetData() const { return a.data(); }
+};
+/// fem/coefficient.hpp MatrixCoefficient family.  Packed(): the entries the way
+/// CoefficientVector::ProjectTranspose leaves them for the PA setup (fem/coefficient.cpp:2026-2056):
+/// 9 row-major entries of K, or the 6 of the upper triangle for the symmetric classes.
+class MatrixCoefficient
+{
+protected:
+   int height, width;
+public:
+   explicit MatrixCoefficient(int dim) : height(dim), width(dim) {}
+   virtual ~MatrixCoefficient() {}
+   int GetHeight() const { return height; }
+   int GetWidth() const { return width; }
+   virtual bool IsSymmetric() const { return false; }
+   virtual bool IsConstant() const { return false; }
+   /// K at a physical point
+   virtual void EvalAt(const Vector &x, DenseMatrix &K) const = 0;
+   /// packed entries at a physical point: PackedSize() numbers
+   int PackedSize() const { return IsSymmetric() ? height*(height + 1)/2 : height*width; }
+   virtual void PackedAt(const Vector &x, real_t *c) const
+   {
+      DenseMatrix K; EvalAt(x, K);
+      for (int i = 0; i < height; i++) { for (int j = 0; j < width; j++) { c[i*width + j] = K(i, j); } }
+   }
+};
+class MatrixConstantCoefficient : public MatrixCoefficient
+{
+   DenseMatrix mat;
+public:
+   explicit MatrixConstantCoefficient(const DenseMatrix &m) : MatrixCoefficient(m.Height()), mat(m) {}
+   const DenseMatrix &GetMatrix() const { return mat; }
+   bool IsConstant() const override { return true; }
+   void EvalAt(const Vector &, DenseMatrix &K) const override { K = mat; }
+};
+class MatrixFunctionCoefficient : public MatrixCoefficient
+{
+   std::function<void(const Vector &, DenseMatrix &)> F;
+public:
+   MatrixFunctionCoefficient(int dim, std::function<void(const Vector &, DenseMatrix &)> f) : MatrixCoefficient(dim), F(std::move(f)) {}
+   void EvalAt(const Vector &x, DenseMatrix &K) const override { K.SetSize(height, width); F(x, K); }
+};
+class SymmetricMatrixCoefficient : public MatrixCoefficient
+{
+public:
+   explicit SymmetricMatrixCoefficient(int dim) : MatrixCoefficient(dim) {}
+   bool IsSymmetric() const override { return true; }
+   virtual void EvalAt(const Vector &x, DenseSymmetricMatrix &K) const = 0;
+   void EvalAt(const Vector &x, DenseMatrix &K) const override
+   {
+      DenseSymmetricMatrix S; EvalAt(x, S);
+      K.SetSize(height, width);
+      for (int i = 0; i < height; i++) { for (int j = 0; j < width; j++) { K(i, j) = S(i, j); } }
+   }
+   void PackedAt(const Vector &x, real_t *c) const override
+   {
+      DenseSymmetricMatrix S; EvalAt(x, S);
+      for (int k = 0; k < PackedSize(); k++) { c[k] = S.GetData()[k]; }
+   }
+};
+class SymmetricMatrixConstantCoefficient : public SymmetricMatrixCoefficient
+{
+   DenseSymmetricMatrix mat;
+public:
+   explicit SymmetricMatrixConstantCoefficient(const DenseSymmetricMatrix &m) : SymmetricMatrixCoefficient(m.Height()), mat(m) {}
+   const DenseSymmetricMatrix &GetMatrix() const { return mat; }
+   bool IsConstant() const override { return true; }
+   using SymmetricMatrixCoefficient::EvalAt;
+   void EvalAt(const Vector &, DenseSymmetricMatrix &K) const override { K = mat; }
+};
+class SymmetricMatrixFunctionCoefficient : public SymmetricMatrixCoefficient
+{
+   std::function<void(const Vector &, DenseSymmetricMatrix &)> F;
+public:
+   SymmetricMatrixFunctionCoefficient(int dim, std::function<void(const Vector &, DenseSymmetricMatrix &)> f)
+      : SymmetricMatrixCoefficient(dim), F(std::move(f)) {}
+   using SymmetricMatrixCoefficient::EvalAt;
+   void EvalAt(const Vector &x, DenseSymmetricMatrix &K) const override { K.SetSize(height); F(x, K); }
 };
 
 // ---- finite elements: H1 on hexahedra (fem/fe_coll.hpp, fem/fe/fe_h1.cpp) --------------
@@ -790,12 +907,16 @@ protected:
    int kind = -1, dofs1D = 0, quad1D = 0, ne = 0, pa_layout = 1;
    int vdim = 1;                         // components of the space (vector integrators)
    bool vector_integrator = false;
+   bool symmetric = true;                // false: 9-plane D of a full matrix coefficient (fem/bilininteg.hpp:2208)
+   /// operator kind at the C ABI: 0 mass, 1 diffusion, 2 diffusion with the non-symmetric D
+   int OperatorKind() const { return (kind == 1 && !symmetric) ? 2 : kind; }
    const DofToQuad *maps = nullptr;
    Vector pa_data;
    mutable Vector pa_data_mfem;          // MFEM-layout copy, made on the first E-vector AddMultPA
    const Vector &MFEMLayoutData() const;
    explicit BilinearFormIntegrator(const IntegrationRule *ir = nullptr) : IntRule(ir) {}
-   void SetupPA(const FiniteElementSpace &fes, int kind, Coefficient *Q, const IntegrationRule &ir);
+   void SetupPA(const FiniteElementSpace &fes, int kind, Coefficient *Q, const IntegrationRule &ir,
+                VectorCoefficient *VQ = nullptr, MatrixCoefficient *MQ = nullptr);
    friend class PABilinearFormExtension;
 public:
    virtual ~BilinearFormIntegrator() {}
@@ -812,10 +933,17 @@ public:
 /// fem/bilininteg.hpp:2169-2360; PA in fem/integ/bilininteg_diffusion_pa.cpp.
 class DiffusionIntegrator : public BilinearFormIntegrator
 {
-   Coefficient *Q;
+   Coefficient *Q; VectorCoefficient *VQ = nullptr; MatrixCoefficient *MQ = nullptr;
 public:
    DiffusionIntegrator(const IntegrationRule *ir = nullptr) : BilinearFormIntegrator(ir), Q(nullptr) {}
    DiffusionIntegrator(Coefficient &q, const IntegrationRule *ir = nullptr) : BilinearFormIntegrator(ir), Q(&q) {}
+   /// diag(q) as the diffusion tensor (fem/bilininteg.hpp:2282-2291)
+   DiffusionIntegrator(VectorCoefficient &q, const IntegrationRule *ir = nullptr) : BilinearFormIntegrator(ir), Q(nullptr), VQ(&q) {}
+   /// full or symmetric matrix coefficient (fem/bilininteg.hpp:2293-2302)
+   DiffusionIntegrator(MatrixCoefficient &q, const IntegrationRule *ir = nullptr) : BilinearFormIntegrator(ir), Q(nullptr), MQ(&q) {}
+   /// the operator is symmetric only when D is; otherwise aborts as the reference does
+   /// (fem/integ/bilininteg_diffusion_pa.cpp:76-87)
+   void AddMultTransposePA(const Vector &x, Vector &y) const override;
    static const IntegrationRule &GetRule(const FiniteElement &trial_fe, const FiniteElement &test_fe);
    void AssemblePA(const FiniteElementSpace &fes) override;
    void AddMultPA(const Vector &x, Vector &y) const override;

@@ -353,8 +353,9 @@ void orc_det_3d(int Q, int64_t ne, const double *J, double *detJ)
 /* ---------------------------------------------------------------------------------
  * PADiffusionSetup3D (fem/integ/bilininteg_diffusion_kernels.cpp:243-367).
  * coeffDim in {1,3} (scalar / vector coefficient), symmetric 6-component output
- * D(q,k,e), k order (1,1),(2,1),(3,1),(2,2),(3,2),(3,3).  const_c: C has coeffDim
- * entries; else C is (coeffDim,Q,Q,Q,NE).
+ * D(q,k,e), k order (1,1),(2,1),(3,1),(2,2),(3,2),(3,3); coeffDim 6 (symmetric matrix
+ * coefficient, 6 planes out) or 9 (full matrix, 9 row-major planes out), :297-348.
+ * const_c: C has coeffDim entries; else C is (coeffDim,Q,Q,Q,NE).
  * ------------------------------------------------------------------------------ */
 void orc_diffusion_setup_3d(int Q, int coeffDim, int64_t ne, const double *W,
                             const double *J, const double *C, int const_c, double *D)
@@ -382,6 +383,45 @@ void orc_diffusion_setup_3d(int Q, int coeffDim, int64_t ne, const double *W,
          const double A32 = (J31*J12) - (J11*J32);
          const double A33 = (J11*J22) - (J12*J21);
          const double *c = const_c ? C : C + coeffDim*(q + Q3*e);
+         if (coeffDim == 6 || coeffDim == 9)
+         {
+            const int symmetric = coeffDim != 9;
+            const double M11 = c[0], M12 = c[1], M13 = c[2];
+            const double M21 = !symmetric ? c[3] : M12;
+            const double M22 = !symmetric ? c[4] : c[3];
+            const double M23 = !symmetric ? c[5] : c[4];
+            const double M31 = !symmetric ? c[6] : M13;
+            const double M32 = !symmetric ? c[7] : M23;
+            const double M33 = !symmetric ? c[8] : c[5];
+            const double R11 = M11*A11 + M12*A12 + M13*A13;
+            const double R12 = M11*A21 + M12*A22 + M13*A23;
+            const double R13 = M11*A31 + M12*A32 + M13*A33;
+            const double R21 = M21*A11 + M22*A12 + M23*A13;
+            const double R22 = M21*A21 + M22*A22 + M23*A23;
+            const double R23 = M21*A31 + M22*A32 + M23*A33;
+            const double R31 = M31*A11 + M32*A12 + M33*A13;
+            const double R32 = M31*A21 + M32*A22 + M33*A23;
+            const double R33 = M31*A31 + M32*A32 + M33*A33;
+            double *Dm = D + (symmetric ? 6 : 9)*Q3*e + q;
+            const double D12 = w_detJ*(A11*R12 + A12*R22 + A13*R32);
+            const double D22 = w_detJ*(A21*R12 + A22*R22 + A23*R32);
+            const double D23 = w_detJ*(A21*R13 + A22*R23 + A23*R33);
+            const double D33 = w_detJ*(A31*R13 + A32*R23 + A33*R33);
+            Dm[0*Q3] = w_detJ*(A11*R11 + A12*R21 + A13*R31);
+            Dm[1*Q3] = D12;
+            Dm[2*Q3] = w_detJ*(A11*R13 + A12*R23 + A13*R33);
+            Dm[4*Q3] = symmetric ? D23 : D22;
+            Dm[5*Q3] = symmetric ? D33 : D23;
+            if (symmetric) { Dm[3*Q3] = D22; }
+            else
+            {
+               Dm[3*Q3] = w_detJ*(A21*R11 + A22*R21 + A23*R31);
+               Dm[6*Q3] = w_detJ*(A31*R11 + A32*R21 + A33*R31);
+               Dm[7*Q3] = w_detJ*(A31*R12 + A32*R22 + A33*R32);
+               Dm[8*Q3] = D33;
+            }
+            continue;
+         }
          const double C1 = c[0];
          const double C2 = c[coeffDim == 3 ? 1 : 0];
          const double C3 = c[coeffDim == 3 ? 2 : 0];
@@ -416,15 +456,15 @@ void orc_mass_setup_3d(int Q, int64_t ne, const double *W, const double *detJ,
  * PADiffusionApply3D (fem/integ/bilininteg_diffusion_kernels.hpp:795-985), the
  * reference's host loop nest; symmetric D.  Y += A_e X.
  * ------------------------------------------------------------------------------ */
-void orc_diffusion_apply_3d(int D1D, int Q1D, int64_t ne, const double *B,
-                            const double *G, const double *Dd, const double *Xd,
-                            double *Yd)
+static void diffusion_apply_3d(int D1D, int Q1D, int64_t ne, int symmetric, const double *B,
+                               const double *G, const double *Dd, const double *Xd,
+                               double *Yd)
 {
    const int64_t D3 = (int64_t)D1D*D1D*D1D, Q3 = (int64_t)Q1D*Q1D*Q1D;
    #pragma omp parallel for schedule(static)
    for (int64_t e = 0; e < ne; e++)
    {
-      const double *X = Xd + D3*e, *D = Dd + 6*Q3*e;
+      const double *X = Xd + D3*e, *D = Dd + (symmetric ? 6 : 9)*Q3*e;
       double *Y = Yd + D3*e;
       double (*grad)[3] = (double(*)[3])malloc(sizeof(double)*3*Q3);
       double gradXY[MAXQ][MAXQ][3], gradX[MAXQ][3];
@@ -473,12 +513,18 @@ void orc_diffusion_apply_3d(int D1D, int Q1D, int64_t ne, const double *B,
       }
       for (int64_t q = 0; q < Q3; q++)
       {
+         /* plane order, symmetric and full (:903-911) */
          const double O11 = D[q + 0*Q3], O12 = D[q + 1*Q3], O13 = D[q + 2*Q3];
-         const double O22 = D[q + 3*Q3], O23 = D[q + 4*Q3], O33 = D[q + 5*Q3];
+         const double O21 = symmetric ? O12 : D[q + 3*Q3];
+         const double O22 = symmetric ? D[q + 3*Q3] : D[q + 4*Q3];
+         const double O23 = symmetric ? D[q + 4*Q3] : D[q + 5*Q3];
+         const double O31 = symmetric ? O13 : D[q + 6*Q3];
+         const double O32 = symmetric ? O23 : D[q + 7*Q3];
+         const double O33 = symmetric ? D[q + 5*Q3] : D[q + 8*Q3];
          const double gX = grad[q][0], gY = grad[q][1], gZ = grad[q][2];
          grad[q][0] = (O11*gX) + (O12*gY) + (O13*gZ);
-         grad[q][1] = (O12*gX) + (O22*gY) + (O23*gZ);
-         grad[q][2] = (O13*gX) + (O23*gY) + (O33*gZ);
+         grad[q][1] = (O21*gX) + (O22*gY) + (O23*gZ);
+         grad[q][2] = (O31*gX) + (O32*gY) + (O33*gZ);
       }
       for (int qz = 0; qz < Q1D; ++qz)
       {
@@ -525,6 +571,21 @@ void orc_diffusion_apply_3d(int D1D, int Q1D, int64_t ne, const double *B,
       }
       free(grad);
    }
+}
+
+void orc_diffusion_apply_3d(int D1D, int Q1D, int64_t ne, const double *B,
+                            const double *G, const double *Dd, const double *Xd,
+                            double *Yd)
+{
+   diffusion_apply_3d(D1D, Q1D, ne, 1, B, G, Dd, Xd, Yd);
+}
+
+/* the same with the `symmetric` flag of the reference's signature: 0 = D has 9 row-major planes */
+void orc_diffusion_apply_sym_3d(int D1D, int Q1D, int64_t ne, int symmetric, const double *B,
+                                const double *G, const double *Dd, const double *Xd,
+                                double *Yd)
+{
+   diffusion_apply_3d(D1D, Q1D, ne, symmetric, B, G, Dd, Xd, Yd);
 }
 
 /* ---------------------------------------------------------------------------------
@@ -605,14 +666,14 @@ void orc_mass_apply_3d(int D1D, int Q1D, int64_t ne, const double *B, const doub
  * SmemPADiffusionDiagonal3D (fem/integ/bilininteg_diffusion_kernels.hpp:368-484);
  * symmetric index map ksym (:428-431).  Y += diag(A_e).
  * ------------------------------------------------------------------------------ */
-void orc_diffusion_diag_3d(int D1D, int Q1D, int64_t ne, const double *B,
-                           const double *G, const double *Dd, double *Yd)
+static void diffusion_diag_3d(int D1D, int Q1D, int64_t ne, int symmetric, const double *B,
+                              const double *G, const double *Dd, double *Yd)
 {
    const int64_t D3 = (int64_t)D1D*D1D*D1D, Q3 = (int64_t)Q1D*Q1D*Q1D;
    #pragma omp parallel for schedule(static)
    for (int64_t e = 0; e < ne; e++)
    {
-      const double *D = Dd + 6*Q3*e;
+      const double *D = Dd + (symmetric ? 6 : 9)*Q3*e;
       double *Y = Yd + D3*e;
       double *QQD = (double*)malloc(sizeof(double)*Q1D*Q1D*D1D);
       double *QDD = (double*)malloc(sizeof(double)*Q1D*D1D*D1D);
@@ -620,7 +681,8 @@ void orc_diffusion_diag_3d(int D1D, int Q1D, int64_t ne, const double *B,
       {
          for (int j = 0; j < 3; ++j)
          {
-            const int k = j >= i ? 3 - (3-i)*(2-i)/2 + j : 3 - (3-j)*(2-j)/2 + i;
+            const int ksym = j >= i ? 3 - (3-i)*(2-i)/2 + j : 3 - (3-j)*(2-j)/2 + i;
+            const int k = symmetric ? ksym : 3*i + j;
             for (int qx = 0; qx < Q1D; ++qx)
                for (int qy = 0; qy < Q1D; ++qy)
                   for (int dz = 0; dz < D1D; ++dz)
@@ -664,6 +726,18 @@ void orc_diffusion_diag_3d(int D1D, int Q1D, int64_t ne, const double *B,
       }
       free(QQD); free(QDD);
    }
+}
+
+void orc_diffusion_diag_3d(int D1D, int Q1D, int64_t ne, const double *B,
+                           const double *G, const double *Dd, double *Yd)
+{
+   diffusion_diag_3d(D1D, Q1D, ne, 1, B, G, Dd, Yd);
+}
+
+void orc_diffusion_diag_sym_3d(int D1D, int Q1D, int64_t ne, int symmetric, const double *B,
+                               const double *G, const double *Dd, double *Yd)
+{
+   diffusion_diag_3d(D1D, Q1D, ne, symmetric, B, G, Dd, Yd);
 }
 
 /* SmemPAMassAssembleDiagonal3D (fem/integ/bilininteg_mass_kernels.hpp:324-408). */
@@ -855,7 +929,7 @@ void orc_pa_mult(const orc_op *op, const double *x, double *y)
    orc_restriction_mult(nE, nd, 1, 0, op->ndofs, op->gather_map, x, op->xE);
    memset(op->yE, 0, sizeof(double)*nE);
    if (op->kind == 0) { orc_mass_apply_3d(op->D1D, op->Q1D, op->ne, op->B, op->pa_data, op->xE, op->yE); }
-   else { orc_diffusion_apply_3d(op->D1D, op->Q1D, op->ne, op->B, op->G, op->pa_data, op->xE, op->yE); }
+   else { diffusion_apply_3d(op->D1D, op->Q1D, op->ne, op->kind != 2, op->B, op->G, op->pa_data, op->xE, op->yE); }   /* kind 2: full D */
    orc_restriction_mult_transpose(op->ndofs, op->offsets, op->indices, op->yE, y, 0, 0);
 }
 
@@ -866,7 +940,7 @@ void orc_pa_diag(const orc_op *op, double *diag)
    const int nd = op->D1D*op->D1D*op->D1D;
    memset(op->yE, 0, sizeof(double)*op->ne*nd);
    if (op->kind == 0) { orc_mass_diag_3d(op->D1D, op->Q1D, op->ne, op->B, op->pa_data, op->yE); }
-   else { orc_diffusion_diag_3d(op->D1D, op->Q1D, op->ne, op->B, op->G, op->pa_data, op->yE); }
+   else { diffusion_diag_3d(op->D1D, op->Q1D, op->ne, op->kind != 2, op->B, op->G, op->pa_data, op->yE); }
    orc_restriction_mult_transpose(op->ndofs, op->offsets, op->indices, op->yE, diag, 0, 1);
 }
 

@@ -54,6 +54,8 @@ _sig("orc_mass_setup_3d", None, C.c_int, i64, _d, _d, _d, C.c_int, _d)
 _sig("orc_diffusion_apply_3d", None, C.c_int, C.c_int, i64, _d, _d, _d, _d, _d)
 _sig("orc_mass_apply_3d", None, C.c_int, C.c_int, i64, _d, _d, _d, _d)
 _sig("orc_diffusion_diag_3d", None, C.c_int, C.c_int, i64, _d, _d, _d, _d)
+_sig("orc_diffusion_apply_sym_3d", None, C.c_int, C.c_int, i64, C.c_int, _d, _d, _d, _d, _d)
+_sig("orc_diffusion_diag_sym_3d", None, C.c_int, C.c_int, i64, C.c_int, _d, _d, _d, _d)
 _sig("orc_mass_diag_3d", None, C.c_int, C.c_int, i64, _d, _d, _d)
 _sig("orc_domain_lf_3d", None, C.c_int, C.c_int, i64, _d, _d, _d, C.c_double, _d)
 _sig("orc_restriction_mult_transpose_vdim", None, i64, C.c_int, C.c_int, C.c_int, _i, _i, _d, _d, C.c_int, C.c_int)
