@@ -6,6 +6,7 @@ Jacobi-PCG.  Serial, or one box per rank with the exchange of mfem_amd/parallel.
 torch supplies device memory and the stream; every computation is a HIP kernel of
 libmfem_amd.so."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -41,8 +42,33 @@ class BakeoffProblem:
         self.ndofs = pr.ndofs*vd                      # unknowns (vdofs of a vector problem)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
         self.stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
-        self.gm, self.off, self.ind = t(pr.gather_map), t(pr.offsets), t(pr.indices)
-        nodesE, Wd, one = t(pr.nodes_E), t(W), torch.ones(1, dtype=torch.float64, device=self.dev)
+        gather_map, offsets, indices, nodes_E = pr.gather_map, pr.offsets, pr.indices, pr.nodes_E
+        # Exchange/compute overlap: elements that touch no ghost dof come first, so that their
+        # part of the apply runs while the owner -> ghost exchange is in flight on a second stream.
+        self.e_split = 0
+        if part is not None and exchange is not None and os.environ.get("MFEM_AMD_OVERLAP", "1") != "0":
+            gmap = np.asarray(gather_map).reshape(self.ne, D**3)
+            iface = np.asarray(part.ghost, bool)[gmap].any(axis=1)
+            n_int = int((~iface).sum())
+            # the blocked pa_data layout is addressed per batch of NBZ elements: split on a batch boundary
+            nbz = capi.lib.mfem_amd_pa_data_size(kind, 1, Q, 1)//((6 if kind else 1)*Q**3) if layout else 1
+            self.e_split = (n_int//nbz)*nbz
+            if 0 < self.e_split and iface.any():
+                perm = np.concatenate([np.flatnonzero(~iface), np.flatnonzero(iface)])
+                gmap = gmap[perm]
+                nodes_E = np.asarray(nodes_E).reshape(self.ne, -1)[perm].reshape(-1)
+                gather_map = np.ascontiguousarray(gmap.reshape(-1))
+                # E -> L table of the permuted order: per dof, ascending E-vector position (restriction.cpp:86-99)
+                indices = np.argsort(gather_map, kind="stable").astype(np.int32)
+                offsets = np.zeros(pr.ndofs + 1, np.int32)
+                np.cumsum(np.bincount(gather_map, minlength=pr.ndofs), out=offsets[1:])
+                self._cstream = torch.cuda.Stream(self.dev)
+                self._ev_x, self._ev_ghosts = torch.cuda.Event(), torch.cuda.Event()
+            else:
+                self.e_split = 0
+        self._nodes_E = nodes_E
+        self.gm, self.off, self.ind = t(gather_map), t(offsets), t(indices)
+        nodesE, Wd, one = t(nodes_E), t(W), torch.ones(1, dtype=torch.float64, device=self.dev)
         self.pa = torch.zeros(capi.lib.mfem_amd_pa_data_size(kind, layout, Q, self.ne), dtype=torch.float64, device=self.dev)
         capi.call("mfem_amd_pa_setup_from_nodes_3d", kind, self.Dn, Q, 1, self.ne, Bn, Gn, _p(Wd), _p(nodesE), _p(one), 1,
                   layout, _p(self.pa), None, self.stream)
@@ -77,13 +103,23 @@ class BakeoffProblem:
         self._comm = None
 
     # ---- BilinearForm::Mult (unconstrained L->L), the BK "Kernel" of bench_ceed.cpp:163-190
-    def l2e(self, x):
-        if self.vdim:
-            capi.call("mfem_amd_pa_apply_L2E_vdim", self.kind, self.layout, self.D, self.Q, self.ne, self.vdim, 1, self.nscalar,
-                      self.B, self.G, _p(self.pa), 0, _p(self.gm), None, _p(x), _p(self.yE), self.stream)
+    def l2e(self, x, e0=0, e1=None):
+        """element kernel over the elements [e0, e1) (e0 on a batch boundary of the blocked layout)"""
+        e1 = self.ne if e1 is None else e1
+        if e1 <= e0:
             return
-        capi.call("mfem_amd_pa_apply_L2E", self.kind, self.layout, self.D, self.Q, self.ne, self.B, self.G, _p(self.pa),
-                  _p(self.gm), _p(x), _p(self.yE), self.stream)
+        D3, vd = self.D**3, max(1, self.vdim)
+        nc = 6 if self.kind else 1
+        pa_off = capi.lib.mfem_amd_pa_data_size(self.kind, 1, self.Q, e0) if self.layout else e0*nc*self.Q**3
+        pa = C.c_void_p(self.pa.data_ptr() + 8*pa_off)
+        gm = C.c_void_p(self.gm.data_ptr() + 4*e0*D3)
+        yE = C.c_void_p(self.yE.data_ptr() + 8*e0*D3*vd)
+        if self.vdim:
+            capi.call("mfem_amd_pa_apply_L2E_vdim", self.kind, self.layout, self.D, self.Q, e1 - e0, self.vdim, 1, self.nscalar,
+                      self.B, self.G, pa, 0, gm, None, _p(x), yE, self.stream)
+            return
+        capi.call("mfem_amd_pa_apply_L2E", self.kind, self.layout, self.D, self.Q, e1 - e0, self.B, self.G, pa,
+                  gm, _p(x), yE, self.stream)
 
     def e2l(self, y):
         if self.vdim:
@@ -95,6 +131,21 @@ class BakeoffProblem:
     def mult(self, x, y):
         """y = A x; in parallel x's ghost entries are refreshed first and y ends with owners
         summed / ghosts zero (P^T A P)."""
+        if self.ex is not None and self.e_split:
+            # P on a second stream while the elements that read no ghost entry are worked on; the ghost
+            # entries of x are written there, the interior elements never read them
+            cur = torch.cuda.current_stream(self.dev)
+            self._ev_x.record(cur)
+            with torch.cuda.stream(self._cstream):
+                self._cstream.wait_event(self._ev_x)
+                self.ex.forward(x.data_ptr(), C.c_void_p(self._cstream.cuda_stream))
+                self._ev_ghosts.record(self._cstream)
+            self.l2e(x, 0, self.e_split)
+            cur.wait_event(self._ev_ghosts)
+            self.l2e(x, self.e_split, self.ne)
+            self.e2l(y)
+            self.ex.reverse(y.data_ptr(), self.stream)
+            return
         if self.ex is not None:
             self.ex.forward(x.data_ptr(), self.stream)
         self.l2e(x)
@@ -144,7 +195,7 @@ class BakeoffProblem:
         W = np.ascontiguousarray((qw[None, None, :]*qw[None, :, None]*qw[:, None, None]).reshape(-1))
         pam = torch.zeros(capi.lib.mfem_amd_pa_data_size(0, 0, Qm, self.ne), dtype=torch.float64, device=self.dev)
         one = torch.ones(1, dtype=torch.float64, device=self.dev)
-        Wd, nodesE = t(W), t(self.prob.nodes_E)      # keep the device tensors alive across the launch
+        Wd, nodesE = t(W), t(self._nodes_E)      # keep the device tensors alive across the launch
         capi.call("mfem_amd_pa_setup_from_nodes_3d", 0, self.Dn, Qm, 1, self.ne, Bn, Gn, _p(Wd), _p(nodesE), _p(one),
                   1, 0, _p(pam), None, self.stream)
         ones = torch.ones(self.nscalar, dtype=torch.float64, device=self.dev)
