@@ -204,7 +204,8 @@ def test_errors_are_reported(gh):
     B = np.zeros(11*15)
     rc = capi.lib.mfem_amd_pa_mass_apply_3d(11, 15, 1, B, gh.ptr(x), gh.ptr(x), gh.ptr(x), None)
     assert rc != 0 and b"unsupported" in capi.lib.mfem_amd_last_error()
-    rc = capi.lib.mfem_amd_pa_diffusion_apply_3d(3, 4, 1, 0, B, B, gh.ptr(x), gh.ptr(x), gh.ptr(x), None)
+    # the non-symmetric (9-plane) D has no blocked layout: refused before anything is launched
+    rc = capi.lib.mfem_amd_pa_diffusion_diag_3d(3, 4, 1, 0, B, B, gh.ptr(x), 1, gh.ptr(x), None)
     assert rc != 0 and b"symmetric" in capi.lib.mfem_amd_last_error()
     # empty inputs are fine
     capi.call("mfem_amd_restrict_gather", 0, None, None, None, None)
