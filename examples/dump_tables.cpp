@@ -154,7 +154,17 @@ int main(int argc, char **argv)
                                     : ctype == 0 ? (BilinearFormIntegrator*)new DiffusionIntegrator(vq, irp)
                                     : ctype > 0 ? (BilinearFormIntegrator*)new DiffusionIntegrator(*MQs[ctype], irp)
                                     : (BilinearFormIntegrator*)new DiffusionIntegrator(Q, irp);
-      bf.AddDomainIntegrator(bfi);
+      // trailing "markers": the integrator restricted to the elements of attribute 2, attributes 1 + e%2
+      // (tests/unit/fem/test_pa_kernels.cpp "PA Markers")
+      const bool use_markers = argc > a + 5 && std::string(argv[a+5]) == "markers";
+      Array<int> marker(2); marker[0] = 0; marker[1] = 1;
+      if (use_markers)
+      {
+         for (int e = 0; e < NE; e++) { mesh->SetAttribute(e, 1 + e%2); }
+         mesh->SetAttributes();
+         bf.AddDomainIntegrator(bfi, marker);
+      }
+      else { bf.AddDomainIntegrator(bfi); }
       bf.Assemble();
       const int N = fes.GetVSize();
       Vector x(N), y(N), xE(NE*ND), yE(NE*ND), diag(N), diagE(NE*ND);
@@ -165,6 +175,7 @@ int main(int argc, char **argv)
       diagE = 0.0; bfi->AssembleDiagonalPA(diagE);
       dump("y.f64", y.HostRead(), N); dump("xE.f64", xE.HostRead(), xE.Size()); dump("yE.f64", yE.HostRead(), yE.Size());
       dump("diag.f64", diag.HostRead(), N); dump("diagE.f64", diagE.HostRead(), diagE.Size());
+      if (use_markers) { printf("run: markers |y|=%.15e\n", y.Norml2()); delete mesh; return 0; }
       if (nonsym)      // no symmetric solve for the full matrix; the operator through the ConstrainedOperator seam
       {
          Array<int> none;

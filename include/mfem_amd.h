@@ -161,6 +161,18 @@ int mfem_amd_pa_apply_L2E(int kind, int pa_layout, int D1D, int Q1D, int64_t ne,
                           const double *B, const double *G, const double *D,
                           const int *gather_map, const double *x, double *yE, void *stream);
 
+/* Element-attribute markers of a domain integrator (BilinearForm::AddDomainIntegrator(bfi, marker)):
+ * PABilinearFormExtension::AddMultWithMarkers -> AddWithMarkers_ (fem/bilinearform_ext.cpp:807-833,
+ * 753-774): yE(:,e) += xE(:,e) for the elements with markers[attributes[e]-1] != 0, xE being the
+ * integrator's action on a zeroed temporary E-vector.  markers (nmarkers ints), attributes (ne ints):
+ * device. */
+int mfem_amd_evec_add_marked(int64_t ne, int nd, int nmarkers, const int *markers,
+                             const int *attributes, const double *xE, double *yE, void *stream);
+/* The same selection for the diagonal (fem/bilinearform_ext.cpp:374-398): dE(:,e) = 0 for the
+ * elements that are NOT marked. */
+int mfem_amd_evec_zero_unmarked(int64_t ne, int nd, int nmarkers, const int *markers,
+                                const int *attributes, double *dE, void *stream);
+
 /* ---- ConstrainedOperator (linalg/operator.cpp:511-646) --------------------------- */
 
 /* marker[i] = 1 for i in list (constraint_list -> byte marker), others untouched. */

@@ -72,6 +72,8 @@ _SIGS = {
     "mfem_amd_pa_diffusion_diag_3d": (cint, [cint, cint, i64, cint, _hd, _hd, vp, cint, vp, vp]),
     "mfem_amd_pa_mass_diag_3d": (cint, [cint, cint, i64, _hd, vp, cint, vp, vp]),
     "mfem_amd_pa_apply_L2E": (cint, [cint, cint, cint, cint, i64, _hd, _hd, vp, vp, vp, vp, vp]),
+    "mfem_amd_evec_add_marked": (cint, [i64, cint, cint, vp, vp, vp, vp, vp]),
+    "mfem_amd_evec_zero_unmarked": (cint, [i64, cint, cint, vp, vp, vp, vp]),
     "mfem_amd_restrict_scatter_vdim": (cint, [i64, cint, cint, cint, vp, vp, vp, vp, cint, cint, vp]),
     "mfem_amd_pa_apply_L2E_vdim": (cint, [cint, cint, cint, cint, i64, cint, cint, i64, _hd, _hd, vp, i64, vp, vp, vp, vp, vp]),
     "mfem_amd_pa_vector_diffusion_apply_3d": (cint, [cint, cint, i64, cint, cint, _hd, _hd, vp, vp, vp, vp]),

@@ -315,6 +315,23 @@ k_accumulate(const int64_t n, const int *__restrict__ dst, const int *__restrict
    y[k] = sum;
 }
 
+// Element-attribute markers of an integrator (PABilinearFormExtension::AddMultWithMarkers /
+// AssembleDiagonal, fem/bilinearform_ext.cpp:753-774, 374-398): element e takes part when
+// markers[attributes[e] - 1] != 0.  MODE 0: y(:,e) += x(:,e) on marked elements; MODE 1: d(:,e) = 0 on
+// the others.  One thread per E-vector entry.
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_evec_markers(const int64_t n, const int nd, const int nmarkers, const int *__restrict__ markers,
+               const int *__restrict__ attributes, const double *__restrict__ x, double *__restrict__ y)
+{
+   const int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x;
+   if (i >= n) { return; }
+   const int attr = attributes[i/nd];
+   const bool on = attr > 0 && attr <= nmarkers && markers[attr - 1] != 0;
+   if (MODE == 0) { if (on) { y[i] += x[i]; } }
+   else { if (!on) { y[i] = 0.0; } }
+}
+
 static inline unsigned grid_for(int64_t n) { return (unsigned)((n + 255)/256); }
 
 // E->L with the fused dot; nblocks partials are written (fixed by the caller from n only).
@@ -485,5 +502,27 @@ extern "C" int mfem_amd_shared_accumulate(int64_t nuniq, const int *unq_ldof, co
    MFA_REQUIRE(nuniq > 0 && unq_ldof && unq_shr_i && unq_shr_j && shr_buf && y, "shared_accumulate: bad arguments");
    k_accumulate<<<dim3(grid_for(nuniq)), dim3(256), 0, as_stream(stream)>>>(nuniq, unq_ldof, unq_shr_i, unq_shr_j, shr_buf, y);
    MFA_CHECK_LAUNCH("k_accumulate");
+   return 0;
+}
+
+extern "C" int mfem_amd_evec_add_marked(int64_t ne, int nd, int nmarkers, const int *markers,
+                                        const int *attributes, const double *xE, double *yE, void *stream)
+{
+   const int64_t n = ne*nd;
+   if (n == 0) { return 0; }
+   MFA_REQUIRE(ne > 0 && nd > 0 && nmarkers >= 0 && markers && attributes && xE && yE && xE != yE, "evec_add_marked: bad arguments");
+   k_evec_markers<0><<<dim3(grid_for(n)), dim3(256), 0, as_stream(stream)>>>(n, nd, nmarkers, markers, attributes, xE, yE);
+   MFA_CHECK_LAUNCH("k_evec_markers<add>");
+   return 0;
+}
+
+extern "C" int mfem_amd_evec_zero_unmarked(int64_t ne, int nd, int nmarkers, const int *markers,
+                                           const int *attributes, double *dE, void *stream)
+{
+   const int64_t n = ne*nd;
+   if (n == 0) { return 0; }
+   MFA_REQUIRE(ne > 0 && nd > 0 && nmarkers >= 0 && markers && attributes && dE, "evec_zero_unmarked: bad arguments");
+   k_evec_markers<1><<<dim3(grid_for(n)), dim3(256), 0, as_stream(stream)>>>(n, nd, nmarkers, markers, attributes, nullptr, dE);
+   MFA_CHECK_LAUNCH("k_evec_markers<zero>");
    return 0;
 }

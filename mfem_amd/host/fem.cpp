@@ -626,10 +626,27 @@ void PABilinearFormExtension::Assemble()
    localY.SetSize(elem_restrict->Height());
    MFEM_VERIFY(!a->domain_integs.empty(), "the form has no domain integrators");
    for (BilinearFormIntegrator *bfi : a->domain_integs) { bfi->AssemblePA(*fes); }
+   if (HasMarkers())
+   {
+      const Mesh *mesh = fes->GetMesh();
+      elem_attributes.SetSize(mesh->GetNE());
+      for (int e = 0; e < mesh->GetNE(); e++) { elem_attributes[e] = mesh->GetAttribute(e); }
+      for (Array<int> *m : a->domain_markers)
+      {
+         MFEM_VERIFY(!m || m->Size() == mesh->attributes.Max(), "invalid element marker for domain integrator: size "
+                     << (m ? m->Size() : 0) << ", the mesh has attributes up to " << mesh->attributes.Max());
+      }
+   }
+}
+bool PABilinearFormExtension::HasMarkers() const
+{
+   for (const Array<int> *m : a->domain_markers) { if (m) { return true; } }
+   return false;
 }
 const BilinearFormIntegrator *PABilinearFormExtension::SingleIntegrator() const
 {
-   return (a->domain_integs.size() == 1 && a->domain_integs[0]->maps) ? a->domain_integs[0] : nullptr;
+   // the fused kernels take one integrator on every element; markers go through AddMultWithMarkers
+   return (a->domain_integs.size() == 1 && a->domain_integs[0]->maps && !HasMarkers()) ? a->domain_integs[0] : nullptr;
 }
 void PABilinearFormExtension::Mult(const Vector &x, Vector &y) const
 {
@@ -656,7 +673,18 @@ void PABilinearFormExtension::Mult(const Vector &x, Vector &y) const
    {
       elem_restrict->Mult(x, localX);
       localY = 0.0;
-      for (BilinearFormIntegrator *bfi : a->domain_integs) { bfi->AddMultPA(localX, localY); }
+      for (size_t i = 0; i < a->domain_integs.size(); i++)
+      {
+         const Array<int> *m = a->domain_markers[i];
+         if (!m) { a->domain_integs[i]->AddMultPA(localX, localY); continue; }
+         // AddMultWithMarkers (bilinearform_ext.cpp:807-833): the action on a zeroed temporary, marked elements added
+         tmp_evec.SetSize(localY.Size());
+         tmp_evec = 0.0;
+         a->domain_integs[i]->AddMultPA(localX, tmp_evec);
+         const int ne = elem_attributes.Size();
+         MFEM_AMD_CALL(mfem_amd_evec_add_marked(ne, localY.Size()/ne, m->Size(), m->Read(), elem_attributes.Read(),
+                                                tmp_evec.Read(), localY.ReadWrite(), nullptr));
+      }
    }
    elem_restrict->MultTranspose(localY, y);
 }
@@ -691,7 +719,17 @@ void PABilinearFormExtension::AssembleDiagonal(Vector &diag) const
       return;
    }
    localY = 0.0;
-   for (BilinearFormIntegrator *bfi : a->domain_integs) { bfi->AssembleDiagonalPA(localY); }
+   for (size_t i = 0; i < a->domain_integs.size(); i++)
+   {
+      a->domain_integs[i]->AssembleDiagonalPA(localY);
+      if (const Array<int> *m = a->domain_markers[i])
+      {
+         // as the reference (bilinearform_ext.cpp:374-398): the unmarked elements of the accumulated E-diagonal are zeroed
+         const int ne = elem_attributes.Size();
+         MFEM_AMD_CALL(mfem_amd_evec_zero_unmarked(ne, localY.Size()/ne, m->Size(), m->Read(), elem_attributes.Read(),
+                                                   localY.ReadWrite(), nullptr));
+      }
+   }
    elem_restrict->AbsMultTranspose(localY, diag);       // bilinearform_ext.cpp:413-418
 }
 

@@ -711,7 +711,6 @@ class Mesh
    void FinalizeTopology();
    void CheckElementOrientation();
    void Load(std::istream &input, int refine);
-   void SetAttributes();
    void SetNodesFromElementValues(int order, int ordering, const std::vector<real_t> &old_nodes, const std::vector<real_t> &xe_old);
    void SetNodesFromLegacyCubic(const std::vector<real_t> &raw, int ordering);
    void Destroy();
@@ -719,6 +718,8 @@ class Mesh
    friend class FiniteElementSpace;
 public:
    Array<int> attributes, bdr_attributes;
+   /// recompute `attributes` / `bdr_attributes` after SetAttribute / SetBdrAttribute (mesh/mesh.cpp SetAttributes)
+   void SetAttributes();
    Mesh() {}
    /// mesh/mesh.cpp:4944-: "MFEM mesh v1.0" (hexahedra) and "MFEM INLINE mesh v1.0" files.
    explicit Mesh(const std::string &filename, int generate_edges = 0, int refine = 1, bool fix_orientation = true);
@@ -742,6 +743,9 @@ public:
    const int *GetBdrElementVertices(int b) const { return &boundary[4*b]; }
    int GetAttribute(int e) const { return elem_attr[e]; }
    int GetBdrAttribute(int b) const { return bdr_attr[b]; }
+   /// follow with SetAttributes() (mesh/mesh.hpp)
+   void SetAttribute(int e, int attr) { elem_attr[e] = attr; }
+   void SetBdrAttribute(int b, int attr) { bdr_attr[b] = attr; }
    const int *GetElementEdges(int e) const { return &el_to_edge[12*e]; }
    const int *GetElementFaces(int e) const { return &el_to_face[6*e]; }
    int GetBdrElementFaceIndex(int b) const { return be_to_face[b]; }
@@ -1002,6 +1006,9 @@ public:
    void Mult(const Vector &x, Vector &y) const override;
    void MultTranspose(const Vector &x, Vector &y) const override { Mult(x, y); }
    /// single-integrator fast path description for the fused kernels (nullptr otherwise)
+   Array<int> elem_attributes;            // bilinearform_ext.cpp:290-300
+   mutable Vector tmp_evec;
+   bool HasMarkers() const;
    const BilinearFormIntegrator *SingleIntegrator() const;
    const ElementRestriction *GetElementRestriction() const { return elem_restrict; }
    /// description of the operator for the fused kernels; false unless one assembled integrator
@@ -1012,6 +1019,7 @@ class BilinearForm : public Operator
 {
    FiniteElementSpace *fes; AssemblyLevel assembly = AssemblyLevel::LEGACY;
    std::vector<BilinearFormIntegrator*> domain_integs;
+   std::vector<Array<int>*> domain_markers;       // per integrator: NULL or the caller's attribute marker (not owned)
    PABilinearFormExtension *ext = nullptr;
    friend class PABilinearFormExtension;
 public:
@@ -1024,7 +1032,10 @@ public:
    const PABilinearFormExtension *GetPAExtension() const { return ext; }
    void EnableStaticCondensation() { MFEM_ABORT("mfem_amd: static condensation is outside the partial-assembly path"); }
    void EnableSparseMatrixSorting(bool) {}
-   void AddDomainIntegrator(BilinearFormIntegrator *bfi) { domain_integs.push_back(bfi); }
+   void AddDomainIntegrator(BilinearFormIntegrator *bfi) { domain_integs.push_back(bfi); domain_markers.push_back(nullptr); }
+   /// restricted to the elements whose attribute is marked (fem/bilinearform.cpp AddDomainIntegrator(bfi, elem_marker));
+   /// the marker array is referenced, not copied, as in the reference
+   void AddDomainIntegrator(BilinearFormIntegrator *bfi, Array<int> &elem_marker) { domain_integs.push_back(bfi); domain_markers.push_back(&elem_marker); }
    void Assemble(int skip_zeros = 1);
    void Mult(const Vector &x, Vector &y) const override;
    void MultTranspose(const Vector &x, Vector &y) const override { Mult(x, y); }

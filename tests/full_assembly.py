@@ -27,16 +27,17 @@ def geometry(nodes_E, Bn, Gn, Dn, Q, ne):
     return pts, J, np.linalg.det(J)
 
 
-def assemble(kind, D, Q, B, G, W, nodes_E, Bn, Gn, Dn, gather_map, ndofs, coeff=None):
+def assemble(kind, D, Q, B, G, W, nodes_E, Bn, Gn, Dn, gather_map, ndofs, coeff=None, elements=None):
     """Sparse matrix of the mass (kind 0) or diffusion (kind 1) form.  coeff(pts (n,3)) -> (n,) scalar,
-    (n,3) diagonal entries or (n,3,3) matrix K; a(u, v) = int K grad u . grad v, row = test function."""
+    (n,3) diagonal entries or (n,3,3) matrix K; a(u, v) = int K grad u . grad v, row = test function.
+    elements: the subset the integrator acts on (attribute markers), default all."""
     ne = len(gather_map)//D**3
     gm = np.asarray(gather_map).reshape(ne, D**3)
     phi, dphi = tensor_basis(B, G, D, Q)
     pts, J, detJ = geometry(nodes_E, Bn, Gn, Dn, Q, ne)
     w = np.asarray(W).reshape(-1)
     rows, cols, vals = [], [], []
-    for e in range(ne):
+    for e in (range(ne) if elements is None else elements):
         c = np.ones(Q**3) if coeff is None else np.asarray(coeff(pts[e]))
         if kind == 0:
             Ae = np.einsum("q,qi,qj->ij", w*detJ[e]*c, phi, phi)

@@ -8,7 +8,7 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 import full_assembly as fa                                                        # noqa: E402
-from conftest import load_case                                                    # noqa: E402
+from conftest import load_case, splitmix                                                    # noqa: E402
 from test_pa_equals_assembled import cartesian_setup                              # noqa: E402
 
 
@@ -112,3 +112,51 @@ def test_curved_mesh_pa_and_geometric_factors(name):
                                  c["gather_map"], c["offsets"], c["indices"], np.ones(1), 1, 1, c["x"]):
         assert np.linalg.norm(y - A @ c["x"]) < 1e-11*np.linalg.norm(A @ c["x"])
         assert np.linalg.norm(dg - A.diagonal()) < 1e-11*np.linalg.norm(A.diagonal())
+
+
+# ---- element-attribute markers (tests/unit/fem/test_pa_kernels.cpp:696-746 "PA Markers") ---------------
+def test_marker_kernels_select_elements():
+    from gpu_helpers import dev, host, ptr
+    from mfem_amd import capi
+    capi.call("mfem_amd_init", 0)
+    rng = np.random.default_rng(4)
+    ne, nd = 37, 27
+    attr = rng.integers(1, 4, ne).astype(np.int32)
+    attr[5] = 0                                              # non-positive attribute: never marked (:768)
+    markers = np.array([1, 0, 1], np.int32)
+    x, y = rng.random(ne*nd), rng.random(ne*nd)
+    on = np.array([a > 0 and markers[a - 1] != 0 for a in attr])
+    xd, yd, dd = dev(x), dev(y), dev(y)
+    md, ad = dev(markers, np.int32), dev(attr, np.int32)
+    capi.call("mfem_amd_evec_add_marked", ne, nd, 3, ptr(md), ptr(ad), ptr(xd), ptr(yd), None)
+    want = y.reshape(ne, nd) + np.where(on[:, None], x.reshape(ne, nd), 0.0)
+    assert np.array_equal(host(yd).reshape(ne, nd), want)
+    capi.call("mfem_amd_evec_zero_unmarked", ne, nd, 3, ptr(md), ptr(ad), ptr(dd), None)
+    assert np.array_equal(host(dd).reshape(ne, nd), np.where(on[:, None], y.reshape(ne, nd), 0.0))
+
+
+@pytest.mark.parametrize("kind,p", [(0, 2), (1, 2), (1, 3)])
+def test_cxx_forms_with_markers_equal_assembled(kind, p, tmp_path):
+    """BilinearForm::AddDomainIntegrator(bfi, marker) of the C++ layer: Mult, MultTranspose (symmetric forms) and
+    AssembleDiagonal equal the dense assembly over the marked elements (attributes 1 + e%2, marker {0, 1})"""
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    spec = ["cart", "3", "2", "2", "1", "1", "1", "1", str(p), "0", str(kind), "0", "run", "markers"]
+    out = subprocess.run([str(root / "examples/bin/dump_tables"), str(tmp_path)] + spec, capture_output=True, text=True, timeout=300, cwd=str(root))
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    r = {f.stem: np.fromfile(f, dtype=np.int32 if f.suffix == ".i32" else np.float64) for f in tmp_path.iterdir()}
+    # the tables the C++ layer built (MFEM's dof numbering and space-filling element order)
+    gm, B, G, W, Bn, Gn = r["gather_map"], r["B"], r["G"], r["W"], r["nodes_B"], r["nodes_G"]
+    Q = round(len(W)**(1/3)); D = len(B)//Q; Dn = len(Bn)//Q
+    ne, ndofs = len(gm)//D**3, len(r["y"])
+    ngm, nn = r["nodes_gather_map"].reshape(ne, Dn**3), len(r["nodes"])//3
+    comp = (lambda g, c: r["nodes"][3*g + c]) if r["nodes_byvdim"][0] else (lambda g, c: r["nodes"][g + c*nn])
+    nodes_E = np.stack([comp(ngm, c) for c in range(3)], axis=1).reshape(-1)                  # (Dn^3, 3, NE)
+    A = fa.assemble(kind, D, Q, B, G, W, nodes_E, Bn, Gn, Dn, gm, ndofs, elements=range(1, ne, 2))
+    x = splitmix(1, ndofs)
+    assert np.linalg.norm(r["y"] - A @ x) < 1e-12*np.linalg.norm(A @ x)
+    assert np.linalg.norm(r["diag"] - A.diagonal()) < 1e-12*np.linalg.norm(A.diagonal())
+    untouched = np.setdiff1d(np.arange(ndofs), gm.reshape(ne, -1)[1::2].reshape(-1))
+    assert len(untouched) and np.all(r["y"][untouched] == 0.0)
+
