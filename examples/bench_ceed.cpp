@@ -18,7 +18,9 @@ static double now() { return std::chrono::duration<double>(std::chrono::steady_c
 
 static int reps = 20, max_it = 2000, seed = 1;
 static double rtol = 1e-12;
-static bool jacobi = true, lex = false;
+static bool jacobi = true, lex = false, varcoef = false;
+static const char *mesh_file = "";
+static int ref_levels = 0;
 
 static void run_case(int bp, int p, int N);
 
@@ -37,6 +39,10 @@ int main(int argc, char *argv[])
    args.AddOption(&lex, "-lex", "--lexicographic", "-sfc", "--space-filling-curve", "Element ordering of the mesh.");
    args.AddOption(&seed, "-s", "--seed", "Seed of x.Randomize().");
    args.AddOption(&device_config, "-d", "--device", "Device configuration string.");
+   args.AddOption(&mesh_file, "-m", "--mesh", "Hexahedral mesh file instead of the Cartesian box (curved meshes: BASELINE config 4).");
+   args.AddOption(&ref_levels, "-r", "--refine", "Uniform refinement levels of the mesh file.");
+   args.AddOption(&varcoef, "-vc", "--variable-coefficient", "-cc", "--constant-coefficient",
+                  "Coefficient 1 + x^2 + y z at the quadrature points instead of 1 (scalar problems).");
    args.Parse();
    if (!args.Good()) { args.PrintUsage(std::cout); return 1; }
    MFEM_VERIFY(bp >= 1 && bp <= 6, "bp must be 1..6");
@@ -51,18 +57,23 @@ static void run_case(int bp, int p, int N)
    const bool GLL = bp >= 5, mass = bp <= 2;
    const int VDIM = (bp % 2 == 0) ? 3 : 1;
    double t0 = now();
-   Mesh mesh = Mesh::MakeCartesian3D(N, N, N, Element::HEXAHEDRON, 1.0, 1.0, 1.0, !lex);
+   const bool from_file = mesh_file[0] != 0;
+   Mesh mesh = from_file ? Mesh(mesh_file, 1, 1) : Mesh::MakeCartesian3D(N, N, N, Element::HEXAHEDRON, 1.0, 1.0, 1.0, !lex);
+   for (int l = 0; from_file && l < ref_levels; l++) { mesh.UniformRefinement(); }
    H1_FECollection fec(p, 3, BasisType::GaussLobatto);
    FiniteElementSpace fes(&mesh, &fec, VDIM, VDIM == 3 ? Ordering::byVDIM : Ordering::byNODES);
    IntegrationRules irs(0, GLL ? Quadrature1D::GaussLobatto : Quadrature1D::GaussLegendre);
    const IntegrationRule *ir = &irs.Get(Geometry::CUBE, 2*p + (GLL ? -1 : 3));
    ConstantCoefficient one(1.0);
+   FunctionCoefficient var([](const Vector &x) { return 1.0 + x(0)*x(0) + x(1)*x(2); });
+   MFEM_VERIFY(!varcoef || VDIM == 1, "the variable coefficient is wired for the scalar problems");
+   Coefficient &coef = varcoef ? (Coefficient&)var : (Coefficient&)one;
    const int dofs = fes.GetTrueVSize();
    GridFunction x(&fes), y(&fes);
    BilinearForm a(&fes);
    a.SetAssemblyLevel(AssemblyLevel::PARTIAL);
-   if (VDIM == 1 && mass) { a.AddDomainIntegrator(new MassIntegrator(one, ir)); }
-   else if (VDIM == 1) { a.AddDomainIntegrator(new DiffusionIntegrator(one, ir)); }
+   if (VDIM == 1 && mass) { a.AddDomainIntegrator(new MassIntegrator(coef, ir)); }
+   else if (VDIM == 1) { a.AddDomainIntegrator(new DiffusionIntegrator(coef, ir)); }
    else if (mass) { a.AddDomainIntegrator(new VectorMassIntegrator(one, ir)); }
    else { a.AddDomainIntegrator(new VectorDiffusionIntegrator(one, ir)); }
    a.Assemble();
@@ -79,11 +90,12 @@ static void run_case(int bp, int p, int N)
    internal::DeviceSync();
    const double t_apply = (now() - t0)/reps;
    // algorithmic bytes of one L->L apply: NE*(C*Q^3*8 + 2*D^3*4) + N_L*20
-   const double D1 = p + 1, Q1 = ir->n1d, NE = (double)N*N*N;
+   const double D1 = p + 1, Q1 = ir->n1d, NE = (double)mesh.GetNE();
+   if (from_file) { N = 0; }
    // vector spaces: q-data, gather_map and indices once per element; x, y per vdof; offsets per scalar dof
    const double bytes_apply = NE*((mass ? 1 : 6)*Q1*Q1*Q1*8 + 2*D1*D1*D1*4) + 16.0*dofs + 4.0*dofs/VDIM;
-   printf("{\"phase\": \"kernel\", \"bp\": %d, \"p\": %d, \"N\": %d, \"dofs\": %d, \"norm_Ax\": %.15e, \"ms_per_apply\": %.6f, "
-          "\"MDof/s\": %.3f, \"GB/s\": %.1f, \"hbm_frac\": %.4f, \"setup_s\": %.3f}\n", bp, p, N, dofs, ynorm, t_apply*1e3,
+   printf("{\"phase\": \"kernel\", \"bp\": %d, \"p\": %d, \"N\": %d, \"NE\": %d, \"dofs\": %d, \"norm_Ax\": %.15e, \"ms_per_apply\": %.6f, "
+          "\"MDof/s\": %.3f, \"GB/s\": %.1f, \"hbm_frac\": %.4f, \"setup_s\": %.3f}\n", bp, p, N, mesh.GetNE(), dofs, ynorm, t_apply*1e3,
           1e-6*dofs/t_apply, 1e-9*bytes_apply/t_apply, 1e-9*bytes_apply/t_apply/8000.0, t_setup);
 
    // problem: f = 1, homogeneous Dirichlet, (Jacobi-)CG to rtol

@@ -163,3 +163,26 @@ def test_cxx_api_matrix_coefficients(name, tmp_path):
     assert (its, conv) == (c["cg_iters"], c["cg_converged"])
     assert (its_generic, conv_generic) == (its, conv)
     assert _rel(r["X"], c["X"]) < 1e-9 and _rel(r["X_generic"], c["X"]) < 1e-9
+
+
+# ---- BASELINE config 4: BP3 / BP5 on curved, refined hex meshes with a variable coefficient ------------
+def _curved_anchors():
+    return json.loads((ROOT / "tests/golden/baseline_anchors_curved.json").read_text())["cases"]
+
+
+@pytest.mark.parametrize("case", _curved_anchors(), ids=lambda c: "%s-r%d-%s-p%d" % (c["mesh"].split(".")[0], c["levels"], c["problem"], c["p"]))
+def test_curved_variable_coefficient_known_answers(case):
+    """examples/bench_ceed -m <curved mesh> -r <levels> -vc against the numbers the reference produced for the same
+    mesh, refinement, order, rule and coefficient 1 + x^2 + y z (oracle/ref_probe_curved.cpp): |A x| for
+    x.Randomize(1) to 1e-12, Jacobi-PCG iteration count at rel tol 1e-8, |X|, |B|."""
+    args = [str(BIN / "bench_ceed"), "-m", str(ROOT / "tests/golden/meshes" / case["mesh"]), "-r", str(case["levels"]), "-vc",
+            "-bp", case["problem"][2:], "-p", str(case["p"]), "-rtol", "1e-8", "-mi", "4000", "-reps", "3"]
+    out = subprocess.run(args, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    kern, prob = rows[0], rows[1]
+    assert (kern["NE"], kern["dofs"]) == (case["NE"], case["dofs"])
+    assert abs(kern["norm_Ax"] - case["norm_Ax"]) <= 1e-12*case["norm_Ax"]
+    assert abs(prob["norm_B"] - case["norm_B"]) <= 1e-12*case["norm_B"]
+    assert (prob["iterations"], prob["converged"]) == (case["pcg_its"], case["converged"])
+    assert abs(prob["norm_X"] - case["norm_X"]) <= 1e-8*case["norm_X"]
