@@ -46,65 +46,26 @@ k_gather_vdim(const int64_t n, const int nd, const int vd, const int byvdim,
 // device flag; non-zero -> whole kernel is a no-op (converged PCG).
 //
 // The kernel is bound by the latency of its dependent loads (offsets -> indices -> values),
-// not by bytes, so every thread works on SK rows at once, 256 rows apart (each load
-// instruction stays coalesced across the wave): all offsets first, then the first two index
+// not by bytes, so every thread works on several rows at once, 256 rows apart (each load
+// instruction stays coalesced across the wave): all offsets first, then the first NB index
 // entries of every row, then their values -- independent loads in flight together -- before
-// anything is added.  Rows with more than two contributions (edges, vertices) finish through
-// the unrolled row routine.  The additions stay sequential and left to right per row,
+// anything is added.  The additions stay sequential and left to right per row,
 // starting from 0: the reference's order, bit for bit.
-constexpr int SK = 4;
-
-template <int MODE>
-__device__ __forceinline__ double scatter_row(const int o0, const int o1, const int *__restrict__ indices,
-                                              const double *__restrict__ xE)
+// NB index/value pairs of each of SKK rows in flight per thread (NB*SKK = 16 either way: 62 VGPRs, 8 waves/SIMD);
+// entries beyond NB (edges/vertices at high order) follow one by one.
+template <int MODE, bool DOT, int NB, int SKK>
+__device__ __forceinline__ void scatter_rows(const int64_t ndofs, const int *__restrict__ offsets,
+                                             const int *__restrict__ indices, const double *__restrict__ xE,
+                                             double *__restrict__ y, const unsigned char *__restrict__ marker,
+                                             const double *__restrict__ xin, const double *__restrict__ w, double &prod)
 {
-   double v = 0.0;
-   const int n = o1 - o0;
-   if (n <= 0) { return v; }
-   if (n <= 8)
+   for (int64_t base = (int64_t)blockIdx.x*(256*SKK); base < ndofs; base += (int64_t)gridDim.x*(256*SKK))
    {
-      int id[8];
-      double t[8];
-#pragma unroll
-      for (int k = 0; k < 8; k++) { id[k] = indices[o0 + (k < n ? k : (n > 0 ? n - 1 : 0))]; }
-#pragma unroll
-      for (int k = 0; k < 8; k++) { t[k] = xE[id[k] >= 0 ? id[k] : -1 - id[k]]; }
-#pragma unroll
-      for (int k = 0; k < 8; k++)
-      {
-         if (k < n) { v += (id[k] >= 0 || MODE == 2) ? t[k] : -t[k]; }
-      }
-   }
-   else
-   {
-      for (int j = o0; j < o1; j++)
-      {
-         const int idx = indices[j];
-         const double t = xE[idx >= 0 ? idx : -1 - idx];
-         v += (idx >= 0 || MODE == 2) ? t : -t;
-      }
-   }
-   return v;
-}
-
-template <int MODE, bool DOT>
-__global__ void __launch_bounds__(256)
-k_scatter(const int64_t ndofs, const int *__restrict__ offsets,
-          const int *__restrict__ indices, const double *__restrict__ xE,
-          double *__restrict__ y, const unsigned char *__restrict__ marker,
-          const double *__restrict__ xin, const double *__restrict__ w,
-          double *__restrict__ partials, const int *__restrict__ skip)
-{
-   __shared__ double s4[4];
-   if (skip && *skip) { return; }
-   double prod = 0.0;
-   for (int64_t base = (int64_t)blockIdx.x*(256*SK); base < ndofs; base += (int64_t)gridDim.x*(256*SK))
-   {
-      int o0[SK], n[SK], i0[SK], i1[SK];
-      double t0[SK], t1[SK], v[SK];
+      int o0[SKK], n[SKK], id[SKK][NB];
+      double t[SKK][NB], v[SKK];
       const int64_t last = ndofs - 1;
 #pragma unroll
-      for (int j = 0; j < SK; j++)
+      for (int j = 0; j < SKK; j++)
       {
          const int64_t i = base + threadIdx.x + j*256;
          const int64_t ic = i < ndofs ? i : last;          // clamped: loads stay unconditional
@@ -112,31 +73,36 @@ k_scatter(const int64_t ndofs, const int *__restrict__ offsets,
          n[j] = offsets[ic + 1] - o0[j];
       }
 #pragma unroll
-      for (int j = 0; j < SK; j++)
+      for (int j = 0; j < SKK; j++)
       {
-         i0[j] = n[j] > 0 ? indices[o0[j]] : 0;
-         i1[j] = n[j] > 1 ? indices[o0[j] + 1] : i0[j];
+#pragma unroll
+         for (int k = 0; k < NB; k++) { id[j][k] = n[j] > 0 ? indices[o0[j] + (k < n[j] ? k : n[j] - 1)] : 0; }
       }
 #pragma unroll
-      for (int j = 0; j < SK; j++)
+      for (int j = 0; j < SKK; j++)
       {
-         t0[j] = xE[i0[j] >= 0 ? i0[j] : -1 - i0[j]];
-         t1[j] = xE[i1[j] >= 0 ? i1[j] : -1 - i1[j]];
+#pragma unroll
+         for (int k = 0; k < NB; k++) { t[j][k] = xE[id[j][k] >= 0 ? id[j][k] : -1 - id[j][k]]; }
       }
 #pragma unroll
-      for (int j = 0; j < SK; j++)
+      for (int j = 0; j < SKK; j++)
       {
-         if (n[j] <= 2)
+         double a = 0.0;
+#pragma unroll
+         for (int k = 0; k < NB; k++)
          {
-            double a = 0.0;
-            if (n[j] > 0) { a += (i0[j] >= 0 || MODE == 2) ? t0[j] : -t0[j]; }
-            if (n[j] > 1) { a += (i1[j] >= 0 || MODE == 2) ? t1[j] : -t1[j]; }
-            v[j] = a;
+            if (k < n[j]) { a += (id[j][k] >= 0 || MODE == 2) ? t[j][k] : -t[j][k]; }
          }
-         else { v[j] = scatter_row<MODE>(o0[j], o0[j] + n[j], indices, xE); }
+         for (int k = NB; k < n[j]; k++)
+         {
+            const int idx = indices[o0[j] + k];
+            const double tt = xE[idx >= 0 ? idx : -1 - idx];
+            a += (idx >= 0 || MODE == 2) ? tt : -tt;
+         }
+         v[j] = a;
       }
 #pragma unroll
-      for (int j = 0; j < SK; j++)
+      for (int j = 0; j < SKK; j++)
       {
          const int64_t i = base + threadIdx.x + j*256;
          if (i < ndofs)
@@ -153,6 +119,24 @@ k_scatter(const int64_t ndofs, const int *__restrict__ offsets,
          }
       }
    }
+}
+
+template <int MODE, bool DOT>
+__global__ void __launch_bounds__(256)
+k_scatter(const int64_t ndofs, const int *__restrict__ offsets,
+          const int *__restrict__ indices, const double *__restrict__ xE,
+          double *__restrict__ y, const unsigned char *__restrict__ marker,
+          const double *__restrict__ xin, const double *__restrict__ w,
+          double *__restrict__ partials, const int *__restrict__ skip)
+{
+   __shared__ double s4[4];
+   if (skip && *skip) { return; }
+   double prod = 0.0;
+   // the batch depth follows the table's own average row length (a wave-uniform branch): 8 entries of two rows
+   // where rows are long (p <= 2: >= 3 entries on average), 4 entries of four rows otherwise; a third, shallower
+   // body for p >= 7 gained nothing and cost p = 6 registers (profiles/r1/e2l_rows_probe.txt)
+   if ((int64_t)offsets[ndofs] >= 3*ndofs) { scatter_rows<MODE, DOT, 8, 2>(ndofs, offsets, indices, xE, y, marker, xin, w, prod); }
+   else { scatter_rows<MODE, DOT, 4, 4>(ndofs, offsets, indices, xE, y, marker, xin, w, prod); }
    if (DOT)
    {
       const double r = block_sum_256(prod, s4);
@@ -425,7 +409,7 @@ extern "C" int mfem_amd_restrict_scatter(int64_t ndofs, const int *offsets, cons
    if (ndofs == 0) { return 0; }
    MFA_REQUIRE(ndofs > 0 && offsets && indices && xE && y, "restrict_scatter: bad arguments");
    MFA_REQUIRE(!(add && absv), "restrict_scatter: add and abs cannot be combined");
-   const unsigned nb = grid_for(ndofs);
+   const unsigned nb = (unsigned)((ndofs + 1023)/1024);      // four rows per thread (the two-row body loops twice)
    hipStream_t s = as_stream(stream);
    if (absv)
    {

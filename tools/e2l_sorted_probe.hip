@@ -49,6 +49,80 @@ k_segsum(const int64_t ndofs, const int *__restrict__ offsets, const double *__r
    }
 }
 
+// row-driven E->L with NB index/value pairs of every row in flight (the shipped kernel keeps 2), rows longer
+// than NB finish sequentially from entry NB on
+template <int NB, int SK>
+__device__ __forceinline__ void rows_body(const int64_t ndofs, const int *__restrict__ offsets, const int *__restrict__ indices,
+                                          const double *__restrict__ xE, double *__restrict__ y)
+{
+   for (int64_t base = (int64_t)blockIdx.x*(256*SK); base < ndofs; base += (int64_t)gridDim.x*(256*SK))
+   {
+      int o0[SK], n[SK], id[SK][NB];
+      double t[SK][NB], v[SK];
+      const int64_t last = ndofs - 1;
+#pragma unroll
+      for (int j = 0; j < SK; j++)
+      {
+         const int64_t i = base + threadIdx.x + j*256;
+         const int64_t ic = i < ndofs ? i : last;
+         o0[j] = offsets[ic];
+         n[j] = offsets[ic + 1] - o0[j];
+      }
+#pragma unroll
+      for (int j = 0; j < SK; j++)
+#pragma unroll
+         for (int k = 0; k < NB; k++) { id[j][k] = indices[o0[j] + (k < n[j] ? k : (n[j] > 0 ? n[j] - 1 : 0))]; }
+#pragma unroll
+      for (int j = 0; j < SK; j++)
+#pragma unroll
+         for (int k = 0; k < NB; k++) { t[j][k] = xE[id[j][k]]; }
+#pragma unroll
+      for (int j = 0; j < SK; j++)
+      {
+         double a = 0.0;
+#pragma unroll
+         for (int k = 0; k < NB; k++) { if (k < n[j]) { a += t[j][k]; } }
+         for (int k = NB; k < n[j]; k++) { a += xE[indices[o0[j] + k]]; }
+         v[j] = a;
+      }
+#pragma unroll
+      for (int j = 0; j < SK; j++)
+      {
+         const int64_t i = base + threadIdx.x + j*256;
+         if (i < ndofs) { y[i] = v[j]; }
+      }
+   }
+}
+
+template <int NB>
+__global__ void __launch_bounds__(256)
+k_rows(const int64_t ndofs, const int *__restrict__ offsets, const int *__restrict__ indices,
+       const double *__restrict__ xE, double *__restrict__ y)
+{
+   rows_body<NB, 4>(ndofs, offsets, indices, xE, y);
+}
+
+// one kernel, the batch depth chosen from the table's own average row length (a wave-uniform branch)
+__global__ void __launch_bounds__(256)
+k_rows_auto(const int64_t ndofs, const int *__restrict__ offsets, const int *__restrict__ indices,
+            const double *__restrict__ xE, double *__restrict__ y)
+{
+   const int64_t nnz = offsets[ndofs];
+   if (nnz >= 3*ndofs) { rows_body<8, 2>(ndofs, offsets, indices, xE, y); }
+   else { rows_body<4, 4>(ndofs, offsets, indices, xE, y); }
+}
+
+extern "C" int probe_rows(int nb_pairs, int64_t ndofs, const int *offsets, const int *indices, const double *xE, double *y)
+{
+   if (ndofs <= 0 || !offsets || !indices || !xE || !y) { return -1; }
+   const unsigned nb = (unsigned)((ndofs + 256*SK - 1)/(256*SK));
+   if (nb_pairs == 4) { k_rows<4><<<dim3(nb), dim3(256), 0, 0>>>(ndofs, offsets, indices, xE, y); }
+   else if (nb_pairs == 8) { k_rows<8><<<dim3(nb), dim3(256), 0, 0>>>(ndofs, offsets, indices, xE, y); }
+   else if (nb_pairs == 0) { k_rows_auto<<<dim3(nb), dim3(256), 0, 0>>>(ndofs, offsets, indices, xE, y); }
+   else { return -2; }
+   return (int)hipGetLastError();
+}
+
 __global__ void __launch_bounds__(256)
 k_permute(const int64_t n, const int *__restrict__ pos, const double *__restrict__ yE, double *__restrict__ yS)
 {

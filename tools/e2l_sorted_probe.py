@@ -18,6 +18,7 @@ vp, i64 = C.c_void_p, C.c_int64
 lib.probe_segsum.argtypes = [i64, vp, vp, vp]
 lib.probe_permute.argtypes = [i64, vp, vp, vp]
 lib.probe_copy.argtypes = [i64, vp, vp]
+lib.probe_rows.argtypes = [C.c_int, i64, vp, vp, vp, vp]
 capi.call("mfem_amd_init", 0)
 dev = "cuda:0"
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -54,5 +55,12 @@ for p in [int(a) for a in sys.argv[1:]] or [4]:
     t_seg = timed(lambda: lib.probe_segsum(nd, P(off), P(yS), P(y1)))
     t_perm = timed(lambda: lib.probe_permute(ne*D3, P(posd), P(yE), P(yS)))
     t_copy = timed(lambda: lib.probe_copy(ne*D3, P(yE), P(yS)))
+    extra = ""
+    for nbp in (4, 8, 0):
+        y2 = torch.empty_like(y0)
+        assert lib.probe_rows(nbp, nd, P(off), P(ind), P(yE), P(y2)) == 0
+        torch.cuda.synchronize()
+        ok = bool(torch.equal(y0, y2))
+        extra += f" | rows x{nbp} in flight {timed(lambda: lib.probe_rows(nbp, nd, P(off), P(ind), P(yE), P(y2))):.1f} us ({ok})"
     print(f"p={p} n={n} dofs={nd}: row-driven E->L {t_row:.1f} us | segmented sum {t_seg:.1f} us (bit-identical {same}) | "
-          f"scattered store {t_perm:.1f} us vs coalesced copy {t_copy:.1f} us ({ne*D3*8/1e6:.0f} MB E-vector)", flush=True)
+          f"scattered store {t_perm:.1f} us vs coalesced copy {t_copy:.1f} us ({ne*D3*8/1e6:.0f} MB E-vector)" + extra, flush=True)
