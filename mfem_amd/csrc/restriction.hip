@@ -133,10 +133,12 @@ k_scatter(const int64_t ndofs, const int *__restrict__ offsets,
    if (skip && *skip) { return; }
    double prod = 0.0;
    // the batch depth follows the table's own average row length (a wave-uniform branch): 8 entries of two rows
-   // where rows are long (p <= 2: >= 3 entries on average), 4 entries of four rows otherwise; a third, shallower
-   // body for p >= 7 gained nothing and cost p = 6 registers (profiles/r1/e2l_rows_probe.txt)
-   if ((int64_t)offsets[ndofs] >= 3*ndofs) { scatter_rows<MODE, DOT, 8, 2>(ndofs, offsets, indices, xE, y, marker, xin, w, prod); }
-   else { scatter_rows<MODE, DOT, 4, 4>(ndofs, offsets, indices, xE, y, marker, xin, w, prod); }
+   // where rows are long (p <= 2: >= 3 entries on average), 4 entries of four rows in between, 2 entries of four
+   // rows where most rows are interior dofs (p >= 7: < 1.55 on average)  (profiles/r1/e2l_rows_probe.txt)
+   const int64_t nnz = offsets[ndofs];
+   if (nnz >= 3*ndofs) { scatter_rows<MODE, DOT, 8, 2>(ndofs, offsets, indices, xE, y, marker, xin, w, prod); }
+   else if (20*nnz >= 31*ndofs) { scatter_rows<MODE, DOT, 4, 4>(ndofs, offsets, indices, xE, y, marker, xin, w, prod); }
+   else { scatter_rows<MODE, DOT, 2, 4>(ndofs, offsets, indices, xE, y, marker, xin, w, prod); }
    if (DOT)
    {
       const double r = block_sum_256(prod, s4);

@@ -94,12 +94,12 @@ __device__ __forceinline__ void rows_body(const int64_t ndofs, const int *__rest
    }
 }
 
-template <int NB>
+template <int NB, int SKK = 4>
 __global__ void __launch_bounds__(256)
 k_rows(const int64_t ndofs, const int *__restrict__ offsets, const int *__restrict__ indices,
        const double *__restrict__ xE, double *__restrict__ y)
 {
-   rows_body<NB, 4>(ndofs, offsets, indices, xE, y);
+   rows_body<NB, SKK>(ndofs, offsets, indices, xE, y);
 }
 
 // one kernel, the batch depth chosen from the table's own average row length (a wave-uniform branch)
@@ -118,6 +118,15 @@ extern "C" int probe_rows(int nb_pairs, int64_t ndofs, const int *offsets, const
    const unsigned nb = (unsigned)((ndofs + 256*SK - 1)/(256*SK));
    if (nb_pairs == 4) { k_rows<4><<<dim3(nb), dim3(256), 0, 0>>>(ndofs, offsets, indices, xE, y); }
    else if (nb_pairs == 8) { k_rows<8><<<dim3(nb), dim3(256), 0, 0>>>(ndofs, offsets, indices, xE, y); }
+   else if (nb_pairs >= 100)      // 100*NB + SKK
+   {
+      const int NBv = nb_pairs/100, SKv = nb_pairs % 100;
+      const unsigned g = (unsigned)((ndofs + 256*SKv - 1)/(256*SKv));
+#define V(A, B) if (NBv == A && SKv == B) { k_rows<A, B><<<dim3(g), dim3(256), 0, 0>>>(ndofs, offsets, indices, xE, y); return (int)hipGetLastError(); }
+      V(4, 6) V(4, 8) V(3, 4) V(3, 6) V(3, 8) V(2, 8) V(2, 4) V(6, 2) V(6, 3) V(4, 2) V(4, 3) V(5, 3)
+#undef V
+      return -3;
+   }
    else if (nb_pairs == 0) { k_rows_auto<<<dim3(nb), dim3(256), 0, 0>>>(ndofs, offsets, indices, xE, y); }
    else { return -2; }
    return (int)hipGetLastError();

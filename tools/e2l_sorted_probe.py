@@ -56,7 +56,7 @@ for p in [int(a) for a in sys.argv[1:]] or [4]:
     t_perm = timed(lambda: lib.probe_permute(ne*D3, P(posd), P(yE), P(yS)))
     t_copy = timed(lambda: lib.probe_copy(ne*D3, P(yE), P(yS)))
     extra = ""
-    for nbp in (4, 8, 0):
+    for nbp in [int(v) for v in __import__('os').environ.get('E2L_VARIANTS', '4,8,0').split(',')]:
         y2 = torch.empty_like(y0)
         assert lib.probe_rows(nbp, nd, P(off), P(ind), P(yE), P(y2)) == 0
         torch.cuda.synchronize()
