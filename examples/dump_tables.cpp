@@ -181,6 +181,8 @@ int main(int argc, char **argv)
          Array<int> none;
          OperatorPtr A0; bf.FormSystemMatrix(none, A0);
          Vector cy(N); A0->Mult(x, cy); dump("y_constrained.f64", cy.HostRead(), N);
+         // trailing "transpose": MultTranspose of a non-symmetric form aborts, as in the reference
+         if (argc > a + 5 && std::string(argv[a+5]) == "transpose") { Vector ty(N); bf.MultTranspose(x, ty); }
          printf("run: non-symmetric D |y|=%.15e\n", y.Norml2());
          delete mesh;
          return 0;

@@ -757,6 +757,17 @@ void BilinearForm::Mult(const Vector &x, Vector &y) const
    MFEM_VERIFY(ext, "mfem_amd: BilinearForm::Mult needs AssemblyLevel::PARTIAL");
    ext->Mult(x, y);
 }
+// PABilinearFormExtension::MultTranspose -> AddMultTransposePA (fem/bilinearform_ext.cpp:566-640): the mass and
+// the symmetric diffusion integrators are their own transposes; a non-symmetric D aborts as in the reference
+// (fem/integ/bilininteg_diffusion_pa.cpp:76-87)
+void BilinearForm::MultTranspose(const Vector &x, Vector &y) const
+{
+   for (const BilinearFormIntegrator *bfi : domain_integs)
+   {
+      MFEM_VERIFY(bfi->symmetric, "DiffusionIntegrator::AddMultTransposePA only implemented in the symmetric case.");
+   }
+   Mult(x, y);
+}
 void BilinearForm::AssembleDiagonal(Vector &diag) const
 {
    MFEM_VERIFY(ext, "mfem_amd: BilinearForm::AssembleDiagonal needs AssemblyLevel::PARTIAL");

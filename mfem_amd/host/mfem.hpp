@@ -922,6 +922,7 @@ protected:
    void SetupPA(const FiniteElementSpace &fes, int kind, Coefficient *Q, const IntegrationRule &ir,
                 VectorCoefficient *VQ = nullptr, MatrixCoefficient *MQ = nullptr);
    friend class PABilinearFormExtension;
+   friend class BilinearForm;
 public:
    virtual ~BilinearFormIntegrator() {}
    void SetIntRule(const IntegrationRule *ir) { IntRule = ir; }
@@ -1038,7 +1039,7 @@ public:
    void AddDomainIntegrator(BilinearFormIntegrator *bfi, Array<int> &elem_marker) { domain_integs.push_back(bfi); domain_markers.push_back(&elem_marker); }
    void Assemble(int skip_zeros = 1);
    void Mult(const Vector &x, Vector &y) const override;
-   void MultTranspose(const Vector &x, Vector &y) const override { Mult(x, y); }
+   void MultTranspose(const Vector &x, Vector &y) const override;
    void AssembleDiagonal(Vector &diag) const override;
    void FormLinearSystem(const Array<int> &ess_tdof_list, Vector &x, Vector &b, OperatorHandle &A,
                          Vector &X, Vector &B, int copy_interior = 0);

@@ -186,3 +186,12 @@ def test_curved_variable_coefficient_known_answers(case):
     assert abs(prob["norm_B"] - case["norm_B"]) <= 1e-12*case["norm_B"]
     assert (prob["iterations"], prob["converged"]) == (case["pcg_its"], case["converged"])
     assert abs(prob["norm_X"] - case["norm_X"]) <= 1e-8*case["norm_X"]
+
+
+def test_cxx_mult_transpose_of_nonsymmetric_form_aborts(tmp_path):
+    """DiffusionIntegrator::AddMultTransposePA is 'only implemented in the symmetric case'
+    (fem/integ/bilininteg_diffusion_pa.cpp:76-87): the C++ layer aborts with the reference's message"""
+    spec = ["cart", "2", "2", "2", "1", "1", "1", "1", "2", "2", "1", "6", "run", "transpose"]
+    out = subprocess.run([str(BIN / "dump_tables"), str(tmp_path)] + spec, capture_output=True, text=True, timeout=300, cwd=str(ROOT))
+    assert out.returncode != 0
+    assert "only implemented in the symmetric case" in out.stderr + out.stdout
