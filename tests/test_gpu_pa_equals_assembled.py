@@ -39,11 +39,11 @@ def device_operator(kind, D, Q, ne, ndofs, B, G, Bn, Gn, Dn, W, nodes_E, gather_
     return out
 
 
-@pytest.mark.parametrize("n", [1, 2])
+@pytest.mark.parametrize("n,nonaligned", [(1, False), (2, False), (2, True)])
 @pytest.mark.parametrize("p", [1, 2, 3, 4])
 @pytest.mark.parametrize("ctype", list(fa.COEFFS))
-def test_diffusion_pa_equals_assembled(p, n, ctype):
-    prob, D, Q, B, G, Bn, Gn, W = cartesian_setup(p, n)
+def test_diffusion_pa_equals_assembled(p, n, nonaligned, ctype):
+    prob, D, Q, B, G, Bn, Gn, W = cartesian_setup(p, n, nonaligned)
     A = fa.assemble(1, D, Q, B, G, W, prob.nodes_E, Bn, Gn, 2, prob.gather_map, prob.ndofs, fa.COEFFS[ctype][0])
     pts, _, _ = fa.geometry(prob.nodes_E, Bn, Gn, 2, Q, prob.ne)
     C, cd, const_c = fa.packed_coefficient(ctype, pts)

@@ -19,9 +19,18 @@ from mfem_amd.cartesian import CartesianProblem
 from mfem_amd.tables import bakeoff_tables
 
 
-def cartesian_setup(p, n):
-    """ne = n^3 unit-cube mesh, H1 order p, the integrators' default rule (order 2p+2: p+2 Gauss-Legendre points)"""
+def cartesian_setup(p, n, nonaligned=False):
+    """ne = n^3 unit-cube mesh, H1 order p, the integrators' default rule (order 2p+2: p+2 Gauss-Legendre points).
+    nonaligned: the vertices are moved by a skew + twist (the role of MakeCartesianNonaligned in
+    tests/unit/fem/test_pa_coeff.cpp): trilinear elements that are neither axis-aligned nor affine."""
     prob = CartesianProblem(p, n, n, n)
+    if nonaligned:
+        X = np.asarray(prob.nodes_E).reshape(prob.ne, 3, 8).copy()
+        x, y, z = X[:, 0].copy(), X[:, 1].copy(), X[:, 2].copy()
+        X[:, 0] = x + 0.25*y + 0.1*z*z
+        X[:, 1] = y + 0.15*np.sin(1.3*x) - 0.1*z
+        X[:, 2] = z + 0.2*x*y
+        prob.nodes_E = np.ascontiguousarray(X.reshape(-1))
     _, D, Q, B, G, Bn, Gn, W = bakeoff_tables("bp3", p)
     return prob, D, Q, B, G, Bn, Gn, W
 
@@ -34,11 +43,11 @@ def oracle_pa_data(prob, Q, Bn, Gn, W, C, cd, const_c):
     return pa, J
 
 
-@pytest.mark.parametrize("n", [1, 2])
+@pytest.mark.parametrize("n,nonaligned", [(1, False), (2, False), (2, True)])
 @pytest.mark.parametrize("p", [1, 2, 3, 4])
 @pytest.mark.parametrize("ctype", list(fa.COEFFS))
-def test_diffusion_pa_equals_assembled(p, n, ctype):
-    prob, D, Q, B, G, Bn, Gn, W = cartesian_setup(p, n)
+def test_diffusion_pa_equals_assembled(p, n, nonaligned, ctype):
+    prob, D, Q, B, G, Bn, Gn, W = cartesian_setup(p, n, nonaligned)
     A = fa.assemble(1, D, Q, B, G, W, prob.nodes_E, Bn, Gn, 2, prob.gather_map, prob.ndofs, fa.COEFFS[ctype][0])
     pts, _, _ = fa.geometry(prob.nodes_E, Bn, Gn, 2, Q, prob.ne)
     C, cd, const_c = fa.packed_coefficient(ctype, pts)
