@@ -265,9 +265,23 @@ def cpu_baseline(problem, p, seconds):
         el = time.perf_counter() - t0
         if el > seconds:
             break
-    return {"value": ndofs*reps/el/1e9, "unit": "GDOF/s", "cores": int(orc.lib.orc_num_threads()), "kind": "port",
-            "sample": f"{reps} L->L applies of the same operator (p={p}, Q1D={Q}) on a {n}^3 mesh, {ndofs} dofs, "
-                      f"{el:.1f} s, OpenMP over elements"}
+    out = {"value": ndofs*reps/el/1e9, "unit": "GDOF/s", "cores": int(orc.lib.orc_num_threads()), "kind": "port",
+           "sample": f"{reps} L->L applies of the same operator (p={p}, Q1D={Q}) on a {n}^3 mesh, {ndofs} dofs, "
+                     f"{el:.1f} s, OpenMP over elements"}
+    if kind:
+        # the same Jacobi-PCG as the `cg` object (unit source, all-boundary Dirichlet), a fixed number of iterations:
+        # the oracle's apply is threaded, its vector updates and dots are the reference's sequential loops
+        ess = prob.boundary_dofs().astype(np.int32)
+        opc = orc.Operator(kind, D, Q, ne, ndofs, B, G, pa, prob.gather_map, prob.offsets, prob.indices, ess=ess)
+        dinv = orc.jacobi_setup(opc.diag(), ess)
+        b = np.ones(ndofs); b[ess] = 0.0
+        its_cap = 20
+        t0 = time.perf_counter()
+        _, its, _, _ = opc.pcg(b, dinv, 0.0, max_iter=its_cap)
+        elc = time.perf_counter() - t0
+        out["cg_dofs_iter_per_s"] = ndofs*its/elc
+        out["cg_sample"] = f"{its} Jacobi-PCG iterations on the same mesh, {elc:.2f} s"
+    return out
 
 
 if __name__ == "__main__":
