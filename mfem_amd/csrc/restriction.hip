@@ -197,44 +197,103 @@ k_scatter_vec(const ScatVec sv, const int *__restrict__ offsets,
               const double *__restrict__ xin, const double *__restrict__ w,
               double *__restrict__ partials, const int *__restrict__ skip)
 {
-   // One thread per SCALAR dof: its CSR row (offsets, indices, the / and % by nd) is read once for
-   // all components, three components at a time (vdim = 3 is the case that matters); rows of up to
-   // four entries (faces, interiors: most rows at p >= 3) take one batch of loads, longer ones
-   // (edges, vertices: most rows at p <= 2) batches of eight.
-   constexpr int CB = 3;
+   // Threads own SCALAR dofs: a CSR row (offsets, indices, the / and % by nd) is read once for all
+   // components, three components at a time (vdim = 3 is the case that matters).
+   constexpr int CB = 3, NR = 2, NB = 4;
    __shared__ double s4[4];
    if (skip && *skip) { return; }
    const int vd = sv.vd;
    double prod = 0.0;
-   for (int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x; i < sv.ndofs; i += (int64_t)gridDim.x*256)
+   // NR rows per thread, 256 apart; the first NB entries of every row are in flight together for CB components
+   // (as in k_scatter), longer rows (vertices at p >= 3; edges and vertices below) continue four entries at a time
+   for (int64_t ib = (int64_t)blockIdx.x*(256*NR) + threadIdx.x; ib < sv.ndofs; ib += (int64_t)gridDim.x*(256*NR))
    {
-      const int o0 = offsets[i], o1 = offsets[i + 1];
+      int o0[NR], n[NR];
+#pragma unroll
+      for (int r = 0; r < NR; r++)
+      {
+         const int64_t i = ib + r*256;
+         const int64_t ic = i < sv.ndofs ? i : ib;
+         o0[r] = offsets[ic];
+         n[r] = i < sv.ndofs ? offsets[ic + 1] - o0[r] : 0;
+      }
       for (int c0 = 0; c0 < vd; c0 += CB)
       {
-         double v[CB];
+         int id[NR][NB];
+         int64_t base[NR][NB];
+         double t[NR][NB][CB], v[NR][CB];
 #pragma unroll
-         for (int k = 0; k < CB; k++) { v[k] = 0.0; }
-         if (o1 - o0 <= 4) { if (o1 > o0) { scatter_vec_chunk<MODE, 4, CB>(sv, o0, o1 - o0, c0, indices, xE, v); } }
-         else
+         for (int r = 0; r < NR; r++)
          {
-            for (int j0 = o0; j0 < o1; j0 += 8) { scatter_vec_chunk<MODE, 8, CB>(sv, j0, o1 - j0 < 8 ? o1 - j0 : 8, c0, indices, xE, v); }
+#pragma unroll
+            for (int q = 0; q < NB; q++) { id[r][q] = n[r] > 0 ? indices[o0[r] + (q < n[r] ? q : n[r] - 1)] : 0; }
          }
 #pragma unroll
-         for (int k = 0; k < CB; k++)
+         for (int r = 0; r < NR; r++)
          {
-            const int c = c0 + k;
-            if (c < vd)
+#pragma unroll
+            for (int q = 0; q < NB; q++)
             {
-               const int64_t r = sv.byvdim ? i*vd + c : i + c*sv.ndofs;
-               double val = v[k];
-               if (marker)
+               const int64_t a = id[r][q] >= 0 ? id[r][q] : -1 - id[r][q];
+               base[r][q] = (a % sv.nd) + (int64_t)sv.nd*sv.vd*(a/sv.nd);
+            }
+         }
+#pragma unroll
+         for (int r = 0; r < NR; r++)
+         {
+#pragma unroll
+            for (int q = 0; q < NB; q++)
+            {
+#pragma unroll
+               for (int k = 0; k < CB; k++)
                {
-                  const unsigned char mk = marker[r];
-                  if (mk) { val = (mk == 1) ? xin[r] : 0.0; }
+                  const int c = c0 + k < vd ? c0 + k : vd - 1;
+                  t[r][q][k] = xE[base[r][q] + (int64_t)sv.nd*c];
                }
-               if (MODE == 1) { val += y[r]; }
-               y[r] = val;
-               if (DOT) { prod += w[r]*val; }
+            }
+         }
+#pragma unroll
+         for (int r = 0; r < NR; r++)
+         {
+#pragma unroll
+            for (int k = 0; k < CB; k++) { v[r][k] = 0.0; }
+#pragma unroll
+            for (int q = 0; q < NB; q++)
+            {
+               if (q < n[r])
+               {
+#pragma unroll
+                  for (int k = 0; k < CB; k++) { v[r][k] += (id[r][q] >= 0 || MODE == 2) ? t[r][q][k] : -t[r][q][k]; }
+               }
+            }
+            for (int j0 = o0[r] + NB; j0 < o0[r] + n[r]; j0 += 4)
+            {
+               const int m = o0[r] + n[r] - j0;
+               scatter_vec_chunk<MODE, 4, CB>(sv, j0, m < 4 ? m : 4, c0, indices, xE, v[r]);
+            }
+         }
+#pragma unroll
+         for (int r = 0; r < NR; r++)
+         {
+            const int64_t i = ib + r*256;
+            if (i >= sv.ndofs) { continue; }
+#pragma unroll
+            for (int k = 0; k < CB; k++)
+            {
+               const int c = c0 + k;
+               if (c < vd)
+               {
+                  const int64_t row = sv.byvdim ? i*vd + c : i + c*sv.ndofs;
+                  double val = v[r][k];
+                  if (marker)
+                  {
+                     const unsigned char mk = marker[row];
+                     if (mk) { val = (mk == 1) ? xin[row] : 0.0; }
+                  }
+                  if (MODE == 1) { val += y[row]; }
+                  y[row] = val;
+                  if (DOT) { prod += w[row]*val; }
+               }
             }
          }
       }
@@ -371,7 +430,7 @@ extern "C" int mfem_amd_restrict_scatter_vdim(int64_t ndofs, int nd, int vdim, i
    MFA_REQUIRE(!(add && absv), "restrict_scatter_vdim: add and abs cannot be combined");
    MFA_REQUIRE(ndofs*vdim < ((int64_t)1 << 39), "restrict_scatter_vdim: too many vdofs");
    const ScatVec sv = {vdim, byvdim ? 1 : 0, nd, ndofs};
-   const unsigned nb = grid_for(ndofs);
+   const unsigned nb = (unsigned)((ndofs + 511)/512);         // two scalar dofs per thread
    hipStream_t s = as_stream(stream);
    if (absv) { k_scatter_vec<2, false><<<dim3(nb), dim3(256), 0, s>>>(sv, offsets, indices, xE, y, nullptr, nullptr, nullptr, nullptr, nullptr); }
    else if (add) { k_scatter_vec<1, false><<<dim3(nb), dim3(256), 0, s>>>(sv, offsets, indices, xE, y, nullptr, nullptr, nullptr, nullptr, nullptr); }
