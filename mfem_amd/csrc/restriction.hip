@@ -189,23 +189,16 @@ __device__ __forceinline__ void scatter_vec_chunk(const ScatVec &sv, const int j
    }
 }
 
-template <int MODE, bool DOT>
-__global__ void __launch_bounds__(256)
-k_scatter_vec(const ScatVec sv, const int *__restrict__ offsets,
-              const int *__restrict__ indices, const double *__restrict__ xE,
-              double *__restrict__ y, const unsigned char *__restrict__ marker,
-              const double *__restrict__ xin, const double *__restrict__ w,
-              double *__restrict__ partials, const int *__restrict__ skip)
+// NR scalar rows per thread, 256 apart; the first NB entries of every row are in flight together for CB = 3
+// components (as in k_scatter); longer rows continue four entries at a time.
+template <int MODE, bool DOT, int NB, int NR>
+__device__ __forceinline__ void scatter_vec_rows(const ScatVec &sv, const int *__restrict__ offsets,
+                                                 const int *__restrict__ indices, const double *__restrict__ xE,
+                                                 double *__restrict__ y, const unsigned char *__restrict__ marker,
+                                                 const double *__restrict__ xin, const double *__restrict__ w, double &prod)
 {
-   // Threads own SCALAR dofs: a CSR row (offsets, indices, the / and % by nd) is read once for all
-   // components, three components at a time (vdim = 3 is the case that matters).
-   constexpr int CB = 3, NR = 2, NB = 4;
-   __shared__ double s4[4];
-   if (skip && *skip) { return; }
+   constexpr int CB = 3;
    const int vd = sv.vd;
-   double prod = 0.0;
-   // NR rows per thread, 256 apart; the first NB entries of every row are in flight together for CB components
-   // (as in k_scatter), longer rows (vertices at p >= 3; edges and vertices below) continue four entries at a time
    for (int64_t ib = (int64_t)blockIdx.x*(256*NR) + threadIdx.x; ib < sv.ndofs; ib += (int64_t)gridDim.x*(256*NR))
    {
       int o0[NR], n[NR];
@@ -298,6 +291,24 @@ k_scatter_vec(const ScatVec sv, const int *__restrict__ offsets,
          }
       }
    }
+}
+
+template <int MODE, bool DOT>
+__global__ void __launch_bounds__(256)
+k_scatter_vec(const ScatVec sv, const int *__restrict__ offsets,
+              const int *__restrict__ indices, const double *__restrict__ xE,
+              double *__restrict__ y, const unsigned char *__restrict__ marker,
+              const double *__restrict__ xin, const double *__restrict__ w,
+              double *__restrict__ partials, const int *__restrict__ skip)
+{
+   // Threads own SCALAR dofs: a CSR row (offsets, indices, the / and % by nd) is read once for all
+   // components, three components at a time (vdim = 3 is the case that matters).
+   __shared__ double s4[4];
+   if (skip && *skip) { return; }
+   double prod = 0.0;
+   // batch depth from the table's average row length, as in k_scatter (here the deep batch pays only at p = 1)
+   if ((int64_t)offsets[sv.ndofs] >= 4*sv.ndofs) { scatter_vec_rows<MODE, DOT, 8, 1>(sv, offsets, indices, xE, y, marker, xin, w, prod); }
+   else { scatter_vec_rows<MODE, DOT, 4, 2>(sv, offsets, indices, xE, y, marker, xin, w, prod); }
    if (DOT)
    {
       const double r = block_sum_256(prod, s4);
