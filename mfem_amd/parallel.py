@@ -16,7 +16,7 @@ built here -- no MPI/hypre/METIS):
 MI355X mapping: one process per GPU; the transport is ``torch.distributed`` -- backend
 "nccl" is RCCL, so the grouped isend/irecv below become one ncclGroupStart/ncclSend/ncclRecv/
 ncclGroupEnd per exchange and, with <= 7 face/edge/corner neighbours per direction on a
-2x2x2 grid, every neighbour pair has its own xGMI link.  Messages are tiny (a face of a
+2x2x2 grid, every neighbour pair has its own xGMI link (the default transport issues them as one all_to_all_single with zero splits for non-neighbours; MFEM_AMD_EXCHANGE=p2p keeps the grouped isend/irecv).  Messages are tiny (a face of a
 54^3 p=4 box is 47 089 doubles = 377 KB), so the exchange is latency-bound; the all-reduce
 carries one double.  Vectors live on local L-dofs with ghost entries kept at zero, so no
 T-vector <-> L-vector copies exist at all (the reference copies through ``ltdof_ldof``).
@@ -272,6 +272,13 @@ class Exchange:
         self._cb_keep = None
         self._sum_views = {}
         self._ops = {}
+        import os
+        self.use_alltoall = os.environ.get("MFEM_AMD_EXCHANGE", "alltoall") != "p2p"
+        # a peer may appear once per direction only (true for box and general partitions: one list per neighbour)
+        for lst in (part.upper, part.lower):
+            peers = [pr for pr, _ in lst]
+            if len(set(peers)) != len(peers):
+                self.use_alltoall = False
 
     # -- index kernels ---------------------------------------------------------------
     def _ptr(self, v):
@@ -327,8 +334,29 @@ class Exchange:
             sb, rb = send_host, recv_host
         else:
             sb, rb = send_buf, recv_buf
-        # the buffers are persistent, so the P2POp list of a direction is built once (host time per
-        # exchange matters: the messages are tiny and the device work of an apply is ~0.5 ms)
+        if self.use_alltoall:
+            # ONE collective call per exchange: an all-to-all with per-rank split sizes that are zero for
+            # non-neighbours (RCCL issues a grouped ncclSend/ncclRecv for the non-zero ones only).  The
+            # neighbour lists are sorted by rank, so the buffers already are in rank order.  Host time per
+            # exchange matters: the messages are tiny and the device work of an apply is ~0.45 ms.
+            key = ("a2a", sb.data_ptr(), rb.data_ptr())
+            sp = self._ops.get(key)
+            if sp is None:
+                world = dist.get_world_size(self.group)
+                ins, outs = [0]*world, [0]*world
+                for (peer, _), sz in zip(send_list, send_sizes):
+                    ins[peer] += sz
+                for (peer, _), sz in zip(recv_list, recv_sizes):
+                    outs[peer] += sz
+                sp = (ins, outs, sum(ins), sum(outs))
+                self._ops[key] = sp
+            ins, outs, ns, nr = sp
+            dist.all_to_all_single(rb[:nr], sb[:ns], outs, ins, group=self.group)
+            if self.stage:
+                recv_buf.copy_(recv_host)
+            return
+        # point-to-point variant (MFEM_AMD_EXCHANGE=p2p): the buffers are persistent, so the P2POp list of a
+        # direction is built once
         key = (sb.data_ptr(), rb.data_ptr())
         ops = self._ops.get(key)
         if ops is None:

@@ -151,7 +151,21 @@ X, res, hist = bp.pcg(bp.rhs_unit_source(), 1e-10, max_iter=500, check_every=4, 
 sp = BakeoffProblem("bp3", 3, (6, 6, 6), "cuda:0")
 Xs, rs, hs = sp.pcg(sp.rhs_unit_source(), 1e-10, max_iter=500, check_every=4, want_hist=True)
 t = torch.ones(1, dtype=torch.float64, device="cuda:0"); dist.all_reduce(t); dist.barrier()
+# the two transports of Exchange._transfer on RCCL, with the only peer a world of one has (itself): the all-to-all
+# with explicit split sizes on a side stream (as the overlapped apply issues it), and the grouped isend/irecv
+src = torch.arange(5, dtype=torch.float64, device="cuda:0"); dst = torch.zeros(8, dtype=torch.float64, device="cuda:0")
+side = torch.cuda.Stream()
+ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    side.wait_event(ev)
+    dist.all_to_all_single(dst[:5], src[:5], [5], [5])
+    dist.all_to_all_single(dst[5:5], src[:0], [0], [0])
+torch.cuda.current_stream().wait_stream(side)
+dst2 = torch.zeros(5, dtype=torch.float64, device="cuda:0")
+for r in dist.batch_isend_irecv([dist.P2POp(dist.irecv, dst2, 0), dist.P2POp(dist.isend, src, 0)]):
+    r.wait()
 torch.cuda.synchronize()
+assert torch.equal(dst[:5], src) and torch.equal(dst2, src), (dst, dst2)
 assert res.iterations == rs.iterations and res.converged == 1, (res.iterations, rs.iterations)
 assert float((X - Xs).abs().max()) <= 1e-12*float(Xs.abs().max())
 dist.destroy_process_group()
