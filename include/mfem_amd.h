@@ -69,6 +69,16 @@ int mfem_amd_restrict_scatter(int64_t ndofs, const int *offsets, const int *indi
                               const double *xE, double *y, int add, int absv,
                               void *stream);
 
+/* Chunk-pipelined form of the same transpose gather (fem/restriction.cpp:152-180 applied chunk of
+ * elements by chunk): a sub-row is the part of an L-row whose entries lie in one element chunk;
+ * rows[i] = L-row | (1<<30: start from y[row], the partial sum the row's previous sub-row left, instead
+ * of 0) | (1<<31: more sub-rows follow).  Entries [offsets[i], offsets[i+1]) of `indices` address xE.
+ * Sub-rows of a row must be submitted in element order, in launches ordered on `stream`: the additions
+ * are then the reference's, in the reference's order (bit-identical to mfem_amd_restrict_scatter). */
+int mfem_amd_restrict_scatter_subrows(int64_t nsub, const int *rows, const int *offsets,
+                                      const int *indices, const double *xE, double *y,
+                                      void *stream);
+
 /* ---- geometric factors and PA setup --------------------------------------------- */
 
 /* GeometricFactors::Compute, JACOBIANS (mesh/mesh.cpp:15178-15231; Derivatives3D,

@@ -58,6 +58,7 @@ _SIGS = {
     "mfem_amd_restrict_gather": (cint, [i64, vp, vp, vp, vp]),
     "mfem_amd_restrict_gather_vdim": (cint, [i64, cint, cint, cint, i64, vp, vp, vp, vp]),
     "mfem_amd_restrict_scatter": (cint, [i64, vp, vp, vp, vp, cint, cint, vp]),
+    "mfem_amd_restrict_scatter_subrows": (cint, [i64, vp, vp, vp, vp, vp, vp]),
     "mfem_amd_geom_jacobians_3d": (cint, [cint, cint, i64, _hd, _hd, vp, vp, vp]),
     "mfem_amd_geom_det_3d": (cint, [cint, i64, vp, vp, vp]),
     "mfem_amd_diffusion_setup_3d": (cint, [cint, cint, i64, vp, vp, vp, cint, vp, vp]),

@@ -139,7 +139,8 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
    // PERSIST = false: one batch per workgroup (grid = nbatches), nothing prefetched.
    const int SCHED = PERSIST ? sched : 1;
    const int64_t G_ = gridDim.x;
-   const int64_t L = SCHED ? (int64_t)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+   // one batch per workgroup with sched == 2: workgroups b, b+8, ... (one XCD, one L2) take consecutive batches
+   const int64_t L = (PERSIST ? SCHED != 0 : sched != 2) ? (int64_t)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
    const int64_t b0 = SCHED ? L : (L*nbatches)/G_;
    const int64_t b1 = SCHED ? nbatches : ((L + 1)*nbatches)/G_;
    const int64_t bstep = SCHED ? G_ : 1;
@@ -1016,7 +1017,8 @@ static int launch_apply(int64_t ne, const double *B, const double *G, const doub
    if (mode == 0)
    {
       MFA_REQUIRE(nb < (int64_t)2147483647, "pa_apply: too many workgroups (%lld)", (long long)nb);
-      kern1<<<dim3((unsigned)nb), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, 1, bg, Dq, x, gmap, yE, VecArgs{});
+      static const int xcd = (getenv("MFEM_AMD_APPLY_XCD") && atoi(getenv("MFEM_AMD_APPLY_XCD"))) ? 2 : 1;
+      kern1<<<dim3((unsigned)nb), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, xcd, bg, Dq, x, gmap, yE, VecArgs{});
    }
    else
    {

@@ -7,6 +7,7 @@
 // reference's deterministic transpose-offset gather (sequential left-to-right sum from 0
 // over indices[offsets[i]..offsets[i+1])), so results are bit-reproducible -- no atomics.
 #include "common.h"
+#include <cstdlib>
 
 namespace mfa
 {
@@ -57,9 +58,10 @@ template <int MODE, bool DOT, int NB, int SKK>
 __device__ __forceinline__ void scatter_rows(const int64_t ndofs, const int *__restrict__ offsets,
                                              const int *__restrict__ indices, const double *__restrict__ xE,
                                              double *__restrict__ y, const unsigned char *__restrict__ marker,
-                                             const double *__restrict__ xin, const double *__restrict__ w, double &prod)
+                                             const double *__restrict__ xin, const double *__restrict__ w, double &prod,
+                                             const int64_t bid)
 {
-   for (int64_t base = (int64_t)blockIdx.x*(256*SKK); base < ndofs; base += (int64_t)gridDim.x*(256*SKK))
+   for (int64_t base = bid*(256*SKK); base < ndofs; base += (int64_t)gridDim.x*(256*SKK))
    {
       int o0[SKK], n[SKK], id[SKK][NB];
       double t[SKK][NB], v[SKK];
@@ -121,24 +123,254 @@ __device__ __forceinline__ void scatter_rows(const int64_t ndofs, const int *__r
    }
 }
 
+// Block-cooperative form of the same kernel.  The row-per-thread form
+// above walks offsets -> indices -> values as three dependent loads per thread, and a thread's row lengths differ.
+// Here a workgroup takes the SAME 1024 rows (thread t: rows t, t+256, ...: the same d.Ad partial sums, bit for
+// bit), but reads the block's entries -- one contiguous run of `indices` -- one entry per thread and sweep, fully
+// coalesced and balanced, gathers their values into LDS, and only then sums every row from LDS in the reference's
+// order.  Blocks with more than CAP entries (vertex and edge rows of MFEM's numbering) go through in four
+// 256-row parts; a part that still does not fit (valence > CAP/256) is summed straight from memory.
+constexpr int SCAT_CAP = 3072;
+template <int MODE, bool DOT>
+__device__ __forceinline__ void scatter_block_rows(const int64_t ndofs, const int *__restrict__ offsets,
+                                                   const int *__restrict__ indices, const double *__restrict__ xE,
+                                                   double *__restrict__ y, const unsigned char *__restrict__ marker,
+                                                   const double *__restrict__ xin, const double *__restrict__ w,
+                                                   double &prod, double *__restrict__ sval)
+{
+   constexpr int CAP = SCAT_CAP, K = CAP/256;
+   const int t = threadIdx.x;
+   // entries [e_lo, e_lo + cnt) of `indices` -> signed values in sval[0, cnt)   (cnt <= CAP, uniform)
+   auto fill = [&](const int e_lo, const int cnt)
+   {
+      int id[K];
+      double v[K];
+#pragma unroll
+      for (int k = 0; k < K; k++)
+      {
+         if (256*k < cnt) { const int e = t + 256*k; id[k] = indices[e_lo + (e < cnt ? e : cnt - 1)]; }
+      }
+#pragma unroll
+      for (int k = 0; k < K; k++)
+      {
+         if (256*k < cnt) { v[k] = xE[id[k] >= 0 ? id[k] : -1 - id[k]]; }
+      }
+#pragma unroll
+      for (int k = 0; k < K; k++)
+      {
+         const int e = t + 256*k;
+         if (256*k < cnt && e < cnt) { sval[e] = (id[k] >= 0 || MODE == 2) ? v[k] : -v[k]; }
+      }
+   };
+   for (int64_t base = (int64_t)blockIdx.x*1024; base < ndofs; base += (int64_t)gridDim.x*1024)
+   {
+      const int64_t last = ndofs - 1;
+      int o0[4], n[4];
+      double val[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+      {
+         const int64_t i = base + t + j*256;
+         const int64_t ic = i < ndofs ? i : last;
+         o0[j] = offsets[ic];
+         n[j] = i < ndofs ? offsets[ic + 1] - o0[j] : 0;
+      }
+      const int64_t rend = base + 1024 < ndofs ? base + 1024 : ndofs;
+      const int o_lo = offsets[base], nent = offsets[rend] - o_lo;
+      if (nent <= CAP)
+      {
+         if (nent > 0) { fill(o_lo, nent); }
+         __syncthreads();
+#pragma unroll
+         for (int j = 0; j < 4; j++)
+         {
+            double a = 0.0;
+            const double *sv = sval + (o0[j] - o_lo);
+            for (int k = 0; k < n[j]; k++) { a += sv[k]; }
+            val[j] = a;
+         }
+         __syncthreads();
+      }
+      else
+      {
+#pragma unroll
+         for (int j = 0; j < 4; j++)
+         {
+            const int64_t r0 = base + j*256;                               // uniform
+            const int64_t r1 = r0 + 256 < ndofs ? r0 + 256 : ndofs;
+            const int p_lo = r0 < ndofs ? offsets[r0] : 0, pcnt = r0 < ndofs ? offsets[r1] - p_lo : 0;
+            double a = 0.0;
+            if (pcnt <= CAP)
+            {
+               if (pcnt > 0) { fill(p_lo, pcnt); }
+               __syncthreads();
+               const double *sv = sval + (o0[j] - p_lo);
+               for (int k = 0; k < n[j]; k++) { a += sv[k]; }
+               __syncthreads();
+            }
+            else
+            {
+               for (int k = 0; k < n[j]; k++)
+               {
+                  const int idx = indices[o0[j] + k];
+                  const double tt = xE[idx >= 0 ? idx : -1 - idx];
+                  a += (idx >= 0 || MODE == 2) ? tt : -tt;
+               }
+            }
+            val[j] = a;
+         }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+      {
+         const int64_t i = base + t + j*256;
+         if (i < ndofs)
+         {
+            double r = val[j];
+            if (marker)
+            {
+               const unsigned char m = marker[i];
+               if (m) { r = (m == 1) ? xin[i] : 0.0; }
+            }
+            if (MODE == 1) { r += y[i]; }
+            y[i] = r;
+            if (DOT) { prod += w[i]*r; }
+         }
+      }
+   }
+}
+
 template <int MODE, bool DOT>
 __global__ void __launch_bounds__(256)
 k_scatter(const int64_t ndofs, const int *__restrict__ offsets,
           const int *__restrict__ indices, const double *__restrict__ xE,
           double *__restrict__ y, const unsigned char *__restrict__ marker,
           const double *__restrict__ xin, const double *__restrict__ w,
-          double *__restrict__ partials, const int *__restrict__ skip)
+          double *__restrict__ partials, const int *__restrict__ skip, const int flags)
+{
+   __shared__ double sval[SCAT_CAP];
+   __shared__ double s4[4];
+   if (skip && *skip) { return; }
+   double prod = 0.0;
+   // Wave-uniform choice by the table's own average row length nnz/ndofs (profiles/r1/e2l_rows_probe.txt,
+   // profiles/r2/e2l_blk_probe.txt): the block-cooperative form below 6 entries per row (p >= 2); long rows
+   // (p = 1: 8 entries) overflow its LDS tile and are faster row per thread, 8 entries of two rows in flight.
+   const int64_t nnz = offsets[ndofs];
+   // flags & 1: logical block id = XCD-contiguous (tuning aid); the partial sums stay indexed by the logical id
+   const int64_t bid = (flags & 1) ? xcd_remap(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
+   if (!(flags & 2) && nnz < 6*ndofs && !(flags & 1))
+   {
+      scatter_block_rows<MODE, DOT>(ndofs, offsets, indices, xE, y, marker, xin, w, prod, sval);
+   }
+   else if (nnz >= 3*ndofs) { scatter_rows<MODE, DOT, 8, 2>(ndofs, offsets, indices, xE, y, marker, xin, w, prod, bid); }
+   else if (20*nnz >= 31*ndofs) { scatter_rows<MODE, DOT, 4, 4>(ndofs, offsets, indices, xE, y, marker, xin, w, prod, bid); }
+   else { scatter_rows<MODE, DOT, 2, 4>(ndofs, offsets, indices, xE, y, marker, xin, w, prod, bid); }
+   if (DOT)
+   {
+      const double r = block_sum_256(prod, s4);
+      if (threadIdx.x == 0) { partials[bid] = r; }
+   }
+}
+
+// Chunk-pipelined E->L (fem/restriction.cpp:152-180 over element chunks): the element kernel runs over
+// contiguous element chunks that write one slot of a small, re-used E-vector ring, and the rows are summed
+// chunk by chunk while the chunk's E-vector part is still in the caches.  A sub-row is the part of an
+// L-row whose entries lie in ONE chunk; sub-rows of a row are visited in chunk (= element) order, the first
+// starts from 0, every later one from the partial sum the previous left in y -- the same additions in the
+// same order as the reference's sequential left-to-right row sum, bit for bit.
+//   rows[i] = L-row | SUB_CONT (continue from y[row]) | SUB_OPEN (more sub-rows follow: not the final value)
+constexpr int SUB_CONT = 1 << 30;
+constexpr unsigned SUB_OPEN = 1u << 31;
+constexpr int SUB_ROW = SUB_CONT - 1;
+
+template <bool DOT, int NB, int SKK>
+__device__ __forceinline__ void scatter_subrows(const int64_t nsub, const int *__restrict__ rows,
+                                                const int *__restrict__ offsets, const int *__restrict__ indices,
+                                                const double *__restrict__ xE, double *__restrict__ y,
+                                                const unsigned char *__restrict__ marker, const double *__restrict__ xin,
+                                                const double *__restrict__ w, double &prod)
+{
+   for (int64_t base = (int64_t)blockIdx.x*(256*SKK); base < nsub; base += (int64_t)gridDim.x*(256*SKK))
+   {
+      int o0[SKK], n[SKK], id[SKK][NB], code[SKK];
+      double t[SKK][NB], v[SKK];
+      const int64_t last = nsub - 1;
+#pragma unroll
+      for (int j = 0; j < SKK; j++)
+      {
+         const int64_t i = base + threadIdx.x + j*256;
+         const int64_t ic = i < nsub ? i : last;
+         code[j] = rows[ic];
+         o0[j] = offsets[ic];
+         n[j] = offsets[ic + 1] - o0[j];
+      }
+#pragma unroll
+      for (int j = 0; j < SKK; j++)
+      {
+#pragma unroll
+         for (int k = 0; k < NB; k++) { id[j][k] = n[j] > 0 ? indices[o0[j] + (k < n[j] ? k : n[j] - 1)] : 0; }
+      }
+#pragma unroll
+      for (int j = 0; j < SKK; j++)
+      {
+         v[j] = 0.0;
+         if (code[j] & SUB_CONT) { v[j] = y[code[j] & SUB_ROW]; }
+#pragma unroll
+         for (int k = 0; k < NB; k++) { t[j][k] = xE[id[j][k] >= 0 ? id[j][k] : -1 - id[j][k]]; }
+      }
+#pragma unroll
+      for (int j = 0; j < SKK; j++)
+      {
+         double a = v[j];
+#pragma unroll
+         for (int k = 0; k < NB; k++)
+         {
+            if (k < n[j]) { a += id[j][k] >= 0 ? t[j][k] : -t[j][k]; }
+         }
+         for (int k = NB; k < n[j]; k++)
+         {
+            const int idx = indices[o0[j] + k];
+            const double tt = xE[idx >= 0 ? idx : -1 - idx];
+            a += idx >= 0 ? tt : -tt;
+         }
+         v[j] = a;
+      }
+#pragma unroll
+      for (int j = 0; j < SKK; j++)
+      {
+         const int64_t i = base + threadIdx.x + j*256;
+         if (i < nsub)
+         {
+            const int row = code[j] & SUB_ROW;
+            const bool open = ((unsigned)code[j] & SUB_OPEN) != 0;
+            double r = v[j];
+            if (marker && !open)
+            {
+               const unsigned char m = marker[row];
+               if (m) { r = (m == 1) ? xin[row] : 0.0; }
+            }
+            y[row] = r;
+            if (DOT && !open) { prod += w[row]*r; }
+         }
+      }
+   }
+}
+
+template <bool DOT>
+__global__ void __launch_bounds__(256)
+k_scatter_sub(const int64_t nsub, const int *__restrict__ rows, const int *__restrict__ offsets,
+              const int *__restrict__ indices, const double *__restrict__ xE,
+              double *__restrict__ y, const unsigned char *__restrict__ marker,
+              const double *__restrict__ xin, const double *__restrict__ w,
+              double *__restrict__ partials, const int *__restrict__ skip)
 {
    __shared__ double s4[4];
    if (skip && *skip) { return; }
    double prod = 0.0;
-   // the batch depth follows the table's own average row length (a wave-uniform branch): 8 entries of two rows
-   // where rows are long (p <= 2: >= 3 entries on average), 4 entries of four rows in between, 2 entries of four
-   // rows where most rows are interior dofs (p >= 7: < 1.55 on average)  (profiles/r1/e2l_rows_probe.txt)
-   const int64_t nnz = offsets[ndofs];
-   if (nnz >= 3*ndofs) { scatter_rows<MODE, DOT, 8, 2>(ndofs, offsets, indices, xE, y, marker, xin, w, prod); }
-   else if (20*nnz >= 31*ndofs) { scatter_rows<MODE, DOT, 4, 4>(ndofs, offsets, indices, xE, y, marker, xin, w, prod); }
-   else { scatter_rows<MODE, DOT, 2, 4>(ndofs, offsets, indices, xE, y, marker, xin, w, prod); }
+   const int64_t nnz = offsets[nsub] - offsets[0];
+   if (nnz >= 3*nsub) { scatter_subrows<DOT, 8, 2>(nsub, rows, offsets, indices, xE, y, marker, xin, w, prod); }
+   else if (20*nnz >= 31*nsub) { scatter_subrows<DOT, 4, 4>(nsub, rows, offsets, indices, xE, y, marker, xin, w, prod); }
+   else { scatter_subrows<DOT, 2, 4>(nsub, rows, offsets, indices, xE, y, marker, xin, w, prod); }
    if (DOT)
    {
       const double r = block_sum_256(prod, s4);
@@ -390,6 +622,15 @@ k_evec_markers(const int64_t n, const int nd, const int nmarkers, const int *__r
 
 static inline unsigned grid_for(int64_t n) { return (unsigned)((n + 255)/256); }
 
+// tuning aids: MFEM_AMD_SCATTER_XCD=1 XCD-contiguous row blocks with the row-per-thread kernel (measured 2-5 %
+// slower, profiles/r2/xcd_probe.txt); MFEM_AMD_SCATTER_BLK=0 row-per-thread kernel at every order
+static int scatter_flags()
+{
+   static const int v = ((getenv("MFEM_AMD_SCATTER_XCD") && atoi(getenv("MFEM_AMD_SCATTER_XCD"))) ? 1 : 0) |
+                        ((getenv("MFEM_AMD_SCATTER_BLK") && !atoi(getenv("MFEM_AMD_SCATTER_BLK"))) ? 2 : 0);
+   return v;
+}
+
 // E->L with the fused dot; nblocks partials are written (fixed by the caller from n only).
 int scatter_dot(int64_t ndofs, const int *offsets, const int *indices, const double *xE,
                 double *y, const unsigned char *marker, const double *xin, const double *w,
@@ -398,12 +639,12 @@ int scatter_dot(int64_t ndofs, const int *offsets, const int *indices, const dou
    if (w)
    {
       k_scatter<0, true><<<dim3(nblocks), dim3(256), 0, s>>>(ndofs, offsets, indices, xE, y,
-                                                           marker, xin, w, partials, skip);
+                                                           marker, xin, w, partials, skip, scatter_flags());
    }
    else
    {
       k_scatter<0, false><<<dim3(nblocks), dim3(256), 0, s>>>(ndofs, offsets, indices, xE, y,
-                                                            marker, xin, nullptr, nullptr, skip);
+                                                            marker, xin, nullptr, nullptr, skip, scatter_flags());
    }
    MFA_CHECK_LAUNCH("k_scatter");
    return 0;
@@ -486,19 +727,32 @@ extern "C" int mfem_amd_restrict_scatter(int64_t ndofs, const int *offsets, cons
    if (absv)
    {
       k_scatter<2, false><<<dim3(nb), dim3(256), 0, s>>>(ndofs, offsets, indices, xE, y, nullptr,
-                                                       nullptr, nullptr, nullptr, nullptr);
+                                                       nullptr, nullptr, nullptr, nullptr, scatter_flags());
    }
    else if (add)
    {
       k_scatter<1, false><<<dim3(nb), dim3(256), 0, s>>>(ndofs, offsets, indices, xE, y, nullptr,
-                                                       nullptr, nullptr, nullptr, nullptr);
+                                                       nullptr, nullptr, nullptr, nullptr, scatter_flags());
    }
    else
    {
       k_scatter<0, false><<<dim3(nb), dim3(256), 0, s>>>(ndofs, offsets, indices, xE, y, nullptr,
-                                                       nullptr, nullptr, nullptr, nullptr);
+                                                       nullptr, nullptr, nullptr, nullptr, scatter_flags());
    }
    MFA_CHECK_LAUNCH("k_scatter");
+   return 0;
+}
+
+extern "C" int mfem_amd_restrict_scatter_subrows(int64_t nsub, const int *rows, const int *offsets,
+                                                 const int *indices, const double *xE, double *y,
+                                                 void *stream)
+{
+   if (nsub == 0) { return 0; }
+   MFA_REQUIRE(nsub > 0 && rows && offsets && indices && xE && y, "restrict_scatter_subrows: bad arguments");
+   const unsigned nb = (unsigned)((nsub + 1023)/1024);
+   k_scatter_sub<false><<<dim3(nb), dim3(256), 0, as_stream(stream)>>>(nsub, rows, offsets, indices, xE, y, nullptr,
+                                                                       nullptr, nullptr, nullptr, nullptr);
+   MFA_CHECK_LAUNCH("k_scatter_sub");
    return 0;
 }
 
