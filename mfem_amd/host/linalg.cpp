@@ -161,7 +161,66 @@ void OperatorJacobiSmoother::Mult(const Vector &x, Vector &y) const
 }
 
 // ---- CGSolver (linalg/solvers.cpp:869-1050) --------------------------------------------
-static bool IsFinite(real_t v) { return std::isfinite(v); }
+// Generic operator / preconditioner (anything the fused device PCG of the C ABI does not take).  Organised like
+// the device solver (csrc/vector_cg.hip pcg_impl): a state record, one routine per stage of an iteration, and a
+// stop code; the decisions, their order and the messages are the reference's.
+namespace
+{
+enum class PcgStop { None, Converged, NotSPDPreconditioner, ZeroCurvature, MaxIterations };
+
+struct PcgRun
+{
+   const Operator &A; Solver *M; Vector &x, &r, &d, &z;
+   const bool warn;
+   real_t rr = 0.0, rr_prev = 0.0, rr0 = 0.0, dAd = 0.0, threshold = 0.0;   // (B r, r) now / before / initial, (A d, d)
+   int it = 0;
+   std::vector<real_t> &log;
+
+   static void RequireFinite(const char *what, real_t v) { MFEM_VERIFY(std::isfinite(v), what << " = " << v); }
+   // z = B r (or r itself without a preconditioner); returns (B r, r)
+   real_t Precondition()
+   {
+      if (M) { M->Mult(r, z); return r*z; }
+      return r*r;
+   }
+   const Vector &Preconditioned() const { return M ? z : r; }
+   // (A d, d) with the reference's diagnostics; false: the direction has zero curvature, stop
+   bool Curvature()
+   {
+      A.Mult(d, z);
+      dAd = d*z;
+      RequireFinite("den", dAd);
+      if (dAd > 0.0) { return true; }
+      if (warn && d*d > 0.0) { mfem::out << "PCG: The operator is not positive definite. (Ad, d) = " << dAd << '\n'; }
+      return dAd != 0.0;
+   }
+   void WarnPreconditioner(real_t v) const
+   {
+      if (warn) { mfem::out << "PCG: The preconditioner is not positive definite. (Br, r) = " << v << '\n'; }
+   }
+   // x and r along d, new (B r, r), stopping test; then the next direction and its curvature
+   PcgStop Advance()
+   {
+      const real_t alpha = rr_prev/dAd;
+      add(x,  alpha, d, x);
+      add(r, -alpha, z, r);
+      rr = Precondition();
+      RequireFinite("betanom", rr);
+      if (rr < 0.0) { WarnPreconditioner(rr); return PcgStop::NotSPDPreconditioner; }
+      log.push_back(rr);
+      return PcgStop::None;
+   }
+   PcgStop NextDirection(int max_iter)
+   {
+      if (rr <= threshold) { return PcgStop::Converged; }
+      if (++it > max_iter) { return PcgStop::MaxIterations; }
+      add(Preconditioned(), rr/rr_prev, d, d);
+      if (!Curvature()) { return PcgStop::ZeroCurvature; }
+      rr_prev = rr;
+      return PcgStop::None;
+   }
+};
+}
 
 void CGSolver::Mult(const Vector &b, Vector &x) const
 {
@@ -169,74 +228,48 @@ void CGSolver::Mult(const Vector &b, Vector &x) const
    history.clear();
    if (FusedMult(b, x)) { return; }
 
-   // generic operator / preconditioner: the reference's sequence on device vectors
-   const bool it_print = print_level == 1, summary = print_level == 2, first_last = print_level == 3;
-   const bool warnings = print_level >= 0;
-   int i;
-   real_t r0, den, nom, nom0, betanom = 0, alpha, beta;
+   const bool every = print_level == 1, summary = print_level == 2, ends = print_level == 3;
+   auto line = [](int k, real_t v, const char *tail) { mfem::out << "   Iteration : " << std::setw(3) << k << "  (B r, r) = " << v << tail; };
    r.SetSize(width); d.SetSize(width); z.SetSize(width);
+   PcgRun run{*oper, prec, x, r, d, z, print_level >= 0, 0, 0, 0, 0, 0, 0, history};
+
+   // iteration 0: residual, first direction, (B r, r)_0
    if (iterative_mode) { oper->Mult(x, r); subtract(b, r, r); }
    else { r = b; x = 0.0; }
-   if (prec) { prec->Mult(r, z); d = z; }
-   else { d = r; }
-   nom0 = nom = Dot(d, r);
-   if (nom0 >= 0.0) { initial_norm = std::sqrt(nom0); }
-   MFEM_VERIFY(IsFinite(nom), "nom = " << nom);
-   history.push_back(nom);
-   if (it_print || first_last)
-   { mfem::out << "   Iteration : " << std::setw(3) << 0 << "  (B r, r) = " << nom << (first_last ? " ...\n" : "\n"); }
-   if (nom < 0.0)
+   run.rr0 = run.rr = run.rr_prev = run.Precondition();
+   d = run.Preconditioned();
+   if (run.rr0 >= 0.0) { initial_norm = std::sqrt(run.rr0); }
+   PcgRun::RequireFinite("nom", run.rr0);
+   history.push_back(run.rr0);
+   if (every || ends) { line(0, run.rr0, ends ? " ...\n" : "\n"); }
+   converged = false; final_iter = 0;
+   if (run.rr0 < 0.0)
    {
-      if (warnings) { mfem::out << "PCG: The preconditioner is not positive definite. (Br, r) = " << nom << '\n'; }
-      converged = false; final_iter = 0; initial_norm = nom; final_norm = nom;
+      run.WarnPreconditioner(run.rr0);
+      initial_norm = final_norm = run.rr0;
       return;
    }
-   r0 = std::max(nom*rel_tol*rel_tol, abs_tol*abs_tol);
-   if (nom <= r0) { converged = true; final_iter = 0; final_norm = std::sqrt(nom); return; }
-   oper->Mult(d, z);
-   den = Dot(z, d);
-   MFEM_VERIFY(IsFinite(den), "den = " << den);
-   if (den <= 0.0)
+   run.threshold = std::max(run.rr0*rel_tol*rel_tol, abs_tol*abs_tol);
+   final_norm = std::sqrt(run.rr0);
+   if (run.rr0 <= run.threshold) { converged = true; return; }
+   if (!run.Curvature()) { return; }
+
+   run.it = 1;
+   PcgStop stop = PcgStop::None;
+   while (stop == PcgStop::None)
    {
-      if (Dot(d, d) > 0.0 && warnings) { mfem::out << "PCG: The operator is not positive definite. (Ad, d) = " << den << '\n'; }
-      if (den == 0.0) { converged = false; final_iter = 0; final_norm = std::sqrt(nom); return; }
+      stop = run.Advance();
+      if (stop != PcgStop::None) { break; }
+      if (every) { line(run.it, run.rr, ""); mfem::out << std::endl; }
+      stop = run.NextDirection(max_iter);
    }
-   converged = false; final_iter = max_iter;
-   for (i = 1; true; )
-   {
-      alpha = nom/den;
-      add(x,  alpha, d, x);
-      add(r, -alpha, z, r);
-      if (prec) { prec->Mult(r, z); betanom = Dot(r, z); }
-      else { betanom = Dot(r, r); }
-      MFEM_VERIFY(IsFinite(betanom), "betanom = " << betanom);
-      if (betanom < 0.0)
-      {
-         if (warnings) { mfem::out << "PCG: The preconditioner is not positive definite. (Br, r) = " << betanom << '\n'; }
-         converged = false; final_iter = i; break;
-      }
-      history.push_back(betanom);
-      if (it_print) { mfem::out << "   Iteration : " << std::setw(3) << i << "  (B r, r) = " << betanom << std::endl; }
-      if (betanom <= r0) { converged = true; final_iter = i; break; }
-      if (++i > max_iter) { break; }
-      beta = betanom/nom;
-      if (prec) { add(z, beta, d, d); }
-      else { add(r, beta, d, d); }
-      oper->Mult(d, z);
-      den = Dot(d, z);
-      MFEM_VERIFY(IsFinite(den), "den = " << den);
-      if (den <= 0.0)
-      {
-         if (Dot(d, d) > 0.0 && warnings) { mfem::out << "PCG: The operator is not positive definite. (Ad, d) = " << den << '\n'; }
-         if (den == 0.0) { final_iter = i; break; }
-      }
-      nom = betanom;
-   }
-   if (first_last && !it_print) { mfem::out << "   Iteration : " << std::setw(3) << final_iter << "  (B r, r) = " << betanom << '\n'; }
-   if (summary || (warnings && !converged)) { mfem::out << "PCG: Number of iterations: " << final_iter << '\n'; }
-   if (summary || it_print || first_last) { mfem::out << "Average reduction factor = " << std::pow(betanom/nom0, 0.5/final_iter) << '\n'; }
-   if (warnings && !converged) { mfem::out << "PCG: No convergence!" << '\n'; }
-   final_norm = std::sqrt(betanom);
+   converged = stop == PcgStop::Converged;
+   final_iter = stop == PcgStop::MaxIterations ? max_iter : run.it;
+   if (ends && !every) { line(final_iter, run.rr, "\n"); }
+   if (summary || (run.warn && !converged)) { mfem::out << "PCG: Number of iterations: " << final_iter << '\n'; }
+   if (summary || every || ends) { mfem::out << "Average reduction factor = " << std::pow(run.rr/run.rr0, 0.5/final_iter) << '\n'; }
+   if (run.warn && !converged) { mfem::out << "PCG: No convergence!" << '\n'; }
+   final_norm = std::sqrt(run.rr);
 }
 
 void CG(const Operator &A, const Vector &b, Vector &x, int print_iter, int max_num_iter,
