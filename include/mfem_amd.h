@@ -212,6 +212,17 @@ int64_t mfem_amd_reduce_workspace_bytes(void);
  * ws: device workspace of mfem_amd_reduce_workspace_bytes(). */
 int mfem_amd_vec_dot(int64_t n, const double *x, const double *y, double *result,
                      void *ws, void *stream);
+/* mfem_amd_vec_dot for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc): the same two kernels and summation order, hence the same
+ * bits, with the partial sums kept in a 64 KiB device array that the library owns (one per GPU, held until
+ * the process ends) instead of a caller workspace.  No counterpart in the reference.  Calls no hipMalloc /
+ * hipFree.  Limits: n <= MFEM_AMD_DOT_NOALLOC_MAX_N (larger n is refused with an error); devices 0..63.
+ * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two streams) race --
+ * order them on one stream.  The array keeps the last call's partial sums; every entry a call reads it has
+ * written first. */
+#define MFEM_AMD_DOT_NOALLOC_MAX_N ((int64_t)1 << 33)
+int mfem_amd_vec_dot_noalloc(int64_t n, const double *x, const double *y, double *result,
+                             void *stream);
 /* OperatorJacobiSmoother::Setup (linalg/solvers.cpp:401-425):
  * dinv[i] = damping/diag[i]; dinv[ess[i]] = damping. */
 int mfem_amd_jacobi_setup(int64_t n, const double *diag, double damping, int64_t ness,

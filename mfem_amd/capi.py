@@ -87,6 +87,7 @@ _SIGS = {
     "mfem_amd_vec_fill": (cint, [i64, dbl, vp, vp]),
     "mfem_amd_reduce_workspace_bytes": (i64, []),
     "mfem_amd_vec_dot": (cint, [i64, vp, vp, vp, vp, vp]),
+    "mfem_amd_vec_dot_noalloc": (cint, [i64, vp, vp, vp, vp]),
     "mfem_amd_jacobi_setup": (cint, [i64, vp, dbl, i64, vp, vp, vp]),
     "mfem_amd_jacobi_apply": (cint, [i64, vp, vp, vp, vp]),
     "mfem_amd_pa_constrained_mult": (cint, [C.POINTER(PaOperator), vp, vp, vp]),

@@ -20,6 +20,8 @@ void set_error(const char *fmt, ...)
    va_end(ap);
 }
 
+int dot_scratch_setup(int dev);      // vector_cg.hip: per-device address of the no-alloc reduction scratch
+
 int check_hip(hipError_t e, const char *what)
 {
    if (e == hipSuccess) { return 0; }
@@ -76,5 +78,6 @@ extern "C" int mfem_amd_init(int device)
                      device, prop.gcnArchName);
       return 1;
    }
+   if (device < 64) { if (int rc = mfa::dot_scratch_setup(device)) { return rc; } }
    return 0;
 }

@@ -293,6 +293,51 @@ extern "C" int mfem_amd_vec_dot(int64_t n, const double *x, const double *y, dou
    return 0;
 }
 
+// ---- mfem_amd_vec_dot for callers that cannot allocate ------------------------------------------------------
+// The partial sums of the reduction live in a file-scope device array instead of a caller-provided workspace.
+// Every GPU holds its own copy of the array at its own address: the address is looked up once per device, with
+// that device current (mfem_amd_init, or the first call on the device), and only that pointer is ever handed to
+// kernels -- the array's name is a host-side stand-in in host code, not a device address.
+static __device__ __align__(256) double scratch[RED_BLOCKS_MAX];     // 64 KiB per GPU, held until the process ends
+static double *g_scratch_ptr[64] = {nullptr};
+
+namespace mfa
+{
+int dot_scratch_setup(int dev)
+{
+   if (dev < 0 || dev >= 64) { set_error("vec_dot_noalloc: device index %d out of range [0, 64)", dev); return 1; }
+   if (g_scratch_ptr[dev]) { return 0; }
+   int cur = -1;
+   if (int rc = check_hip(hipGetDevice(&cur), "hipGetDevice")) { return rc; }
+   if (cur != dev) { set_error("vec_dot_noalloc: device %d must be current (current: %d)", dev, cur); return 1; }
+   double *p = nullptr;
+   if (int rc = check_hip(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)), "hipGetSymbolAddress(scratch)")) { return rc; }
+   if (!p) { set_error("vec_dot_noalloc: hipGetSymbolAddress returned a null address"); return 1; }
+   g_scratch_ptr[dev] = p;
+   return 0;
+}
+}
+
+extern "C" int mfem_amd_vec_dot_noalloc(int64_t n, const double *x, const double *y, double *result, void *stream)
+{
+   MFA_REQUIRE(n >= 0 && result && (n == 0 || (x && y)), "vec_dot_noalloc: bad arguments");
+   MFA_REQUIRE(n <= MFEM_AMD_DOT_NOALLOC_MAX_N, "vec_dot_noalloc: n = %lld exceeds the maximum of %lld entries",
+               (long long)n, (long long)MFEM_AMD_DOT_NOALLOC_MAX_N);
+   int dev = -1;
+   if (int rc = check_hip(hipGetDevice(&dev), "hipGetDevice")) { return rc; }
+   if (int rc = dot_scratch_setup(dev)) { return rc; }
+   double *part = g_scratch_ptr[dev];
+   hipStream_t s = as_stream(stream);
+   // the same two kernels, grid and summation order as mfem_amd_vec_dot: bit-identical result.  Every partial
+   // that the final pass reads (nb of them) is written by this call first, so nothing has to start at zero.
+   const int nb = red_blocks(n);
+   k_dot_partial<<<dim3(nb), dim3(256), 0, s>>>(n, x, y, part);
+   MFA_CHECK_LAUNCH("k_dot_partial");
+   k_dot_final<<<dim3(1), dim3(256), 0, s>>>(nb, part, result);
+   MFA_CHECK_LAUNCH("k_dot_final");
+   return 0;
+}
+
 extern "C" int mfem_amd_jacobi_setup(int64_t n, const double *diag, double damping,
                                      int64_t ness, const int *ess, double *dinv, void *stream)
 {
