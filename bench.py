@@ -24,15 +24,17 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec); ~6.3 TB/s achievable
-# HBM bytes per launch of the dominant kernel from the PMC passes
-# (profiles/r1/bench_p4_pmc_hbm_traffic.txt, tools/pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in
-# separate rocprofv3 --pmc runs of this script, KiB per dispatch averaged over the timed
-# launches).  gfx950 correction of MI355X_MICROARCH.md (HBM section): FETCH_SIZE tallies the
-# 128-B requests of wide streaming reads at 64 B -> doubled; WRITE_SIZE is exact.
-#   k_pa_apply<1,5,6,...>: FETCH_SIZE 9.128e5 KiB, WRITE_SIZE 1.545e5 KiB
-#   -> 2*934.7e6 + 158.2e6 B = 2.028e9 B  (reads +4.3 % over the algorithmic 1.793e9 B,
-#      the rest is the E-vector store the fused-scatter design of DESIGN.md §8 would remove)
-TRAFFIC_BYTES = {("bp3", 4, 54): int(2*9.128e5*1024 + 1.545e5*1024)}
+# HBM bytes per launch of the dominant kernel, from this round's PMC passes over THIS script (tools/pmc_bench.sh:
+# FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs, per dispatch, averaged over the timed launches; gfx950
+# correction of MI355X_MICROARCH.md, HBM section: FETCH_SIZE tallies the 128-B requests of wide streaming reads at
+# 64 B -> doubled, WRITE_SIZE exact).  tools/pmc_summary.py writes bench_traffic.json next to this file with the
+# workload key, the counters and the profile they come from; a workload without an entry reports null.
+def measured_traffic(problem, p, n):
+    f = ROOT / "bench_traffic.json"
+    if not f.exists():
+        return None, None
+    ent = json.loads(f.read_text()).get(f"{problem}_p{p}_n{n}")
+    return (ent["bytes_per_launch"], ent["source"]) if ent else (None, None)
 
 
 def algorithmic_bytes(kind, D, Q, ne, ndofs):
@@ -53,6 +55,7 @@ def main():
     ap.add_argument("--problem", default="bp3", choices=["bp1", "bp2", "bp3", "bp4", "bp5", "bp6"])
     ap.add_argument("--cg-iters", type=int, default=50)
     ap.add_argument("--no-orders", action="store_true", help="skip the p = 1..8 table (N=1 only; ~10 s)")
+    ap.add_argument("--no-sizes", action="store_true", help="skip the BP1/BP3/BP5 x 1e5..1e8 dofs table (N=1 only; ~1 min)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args()
@@ -144,7 +147,8 @@ def main():
     b_l2e, b_e2l = algorithmic_bytes(kind, D, Q, ne, ndofs)
     roof = {"bound": "hbm", "kernel": "k_pa_apply (fused L->E gather + element kernel)",
             "achieved": b_l2e/t_l2e/1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": b_l2e/t_l2e/1e9/HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES.get((args.problem, p, n)),
+            "frac": b_l2e/t_l2e/1e9/HBM_PEAK_GBS, "traffic": measured_traffic(args.problem, p, n)[0],
+            "traffic_source": measured_traffic(args.problem, p, n)[1],
             "algorithmic_bytes_per_launch": b_l2e, "avg_launch_ms": t_l2e*1e3}
     t_apply = el/args.steps
     roof_apply = {"bound": "hbm", "achieved": (b_l2e + b_e2l)/t_apply/1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -177,39 +181,19 @@ def main():
 
     # the metric's "p = 1..8": the same step at every order, ~1e7 dofs each, 20 steps (N = 1 only).  The
     # headline `value` stays the p = 4 workload above; this table rides along in the same JSON line.
-    by_order = None
+    by_order = by_size = None
     if world == 1 and not args.no_orders:
-        by_order = []
         del bp, x, y
         torch.cuda.empty_cache()
-        for q in range(1, 9):
-            nq = max(1, round((1.0e7)**(1.0/3.0)/q))
-            best = None
-            # Two separately allocated attempts, the faster kept: on this platform the SAME kernel on the SAME
-            # data occasionally runs several times slower for one particular placement of its buffers
-            # (last experiment); a second placement (shifted by a pad) does not show it.
-            for attempt in range(2):
-                pad = torch.empty((3 << 20)*attempt + 8, dtype=torch.uint8, device=dev)
-                bq = BakeoffProblem(args.problem, q, (nq, nq, nq), dev)
-                xq = torch.rand(bq.ndofs, dtype=torch.float64, generator=g).to(dev)
-                yq = torch.empty_like(xq)
-                for _ in range(3):
-                    bq.mult(xq, yq)
-                tq = timed(lambda: bq.mult(xq, yq), 20)/20
-                tl = timed(lambda: bq.l2e(xq), 20)/20
-                b1, b2 = algorithmic_bytes(bq.kind, bq.D, bq.Q, bq.ne, bq.ndofs)
-                row = {"p": q, "dofs": bq.ndofs, "GDOF/s": bq.ndofs/tq/1e9, "ms_per_step": tq*1e3,
-                       "apply_frac": (b1 + b2)/tq/1e9/HBM_PEAK_GBS, "l2e_ms": tl*1e3, "l2e_frac": b1/tl/1e9/HBM_PEAK_GBS,
-                       "slower_attempt_ms": None}
-                if best is None:
-                    best = row
-                else:
-                    fast, slow = (row, best) if row["ms_per_step"] < best["ms_per_step"] else (best, row)
-                    fast["slower_attempt_ms"] = slow["ms_per_step"]
-                    best = fast
-                del bq, xq, yq, pad
-                torch.cuda.empty_cache()
-            by_order.append(best)
+        by_order = [size_row(args.problem, q, 1.0e7, dev, g, cg_iters=0) for q in range(1, 9)]
+    # the metric's "1e5 to 1e8 DOFs" for BP1 / BP3 / BP5 (tests/benchmarks/bench_ceed.cpp:142-190) at the headline
+    # order: whole apply and Jacobi-PCG per size.  Below 3e6 dofs the applies are replayed from one HIP graph
+    # (kernel launches from Python cost more than the kernels there).
+    if world == 1 and not args.no_sizes:
+        by_size = []
+        for prob in ("bp1", "bp3", "bp5"):
+            for dofs in (1.0e5, 1.0e6, 1.0e7, 1.0e8):
+                by_size.append(size_row(prob, p, dofs, dev, g, cg_iters=20))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -225,23 +209,84 @@ def main():
                                       f"D1D={D} Q1D={Q}, Cartesian hex mesh {n}^3 per GPU",
                           "elements_per_gpu": ne, "local_dofs_per_gpu": ndofs, "global_dofs": total_dofs,
                           "process_grid": list(pg)},
-               "roofline": roof, "roofline_apply": roof_apply, "cg": cg, "by_order": by_order, "cpu_baseline": cpu,
+               "roofline": roof, "roofline_apply": roof_apply, "cg": cg, "by_order": by_order, "by_size": by_size,
+               "cpu_baseline": cpu,
                "setup_s": setup_s}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
 
+def size_row(problem, p, dofs, dev, gen, cg_iters=20):
+    """One (problem, order, size) line: whole L->L apply (and cg_iters Jacobi-PCG iterations) on an n^3 box with
+    ~dofs unknowns; fractions of the 8 TB/s roofline on SURVEY 8d's algorithmic bytes."""
+    import torch
+    from mfem_amd.bp import BakeoffProblem
+    n = max(1, round(dofs**(1.0/3.0)/p))
+    bq = BakeoffProblem(problem, p, (n, n, n), dev, device_tables=True)
+    xq = torch.rand(bq.ndofs, dtype=torch.float64, generator=gen).to(dev)
+    yq = torch.empty_like(xq)
+    b1, b2 = algorithmic_bytes(bq.kind, bq.D, bq.Q, bq.ne, bq.ndofs)
+    graph = bq.ndofs < 3_000_000
+    # enough applies per timed block for >= ~4 ms of device work
+    k = int(min(400, max(20, 4.0e-3/max(2.0e-6, (b1 + b2)/5.0e12))))
+
+    def ev_time(fn, reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1)*1e-3
+
+    for _ in range(3):
+        bq.mult(xq, yq)
+    torch.cuda.synchronize()
+    if graph:
+        side = torch.cuda.Stream(dev)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            bq.use_stream(side)
+            gr.capture_begin()
+            for _ in range(k):
+                bq.mult(xq, yq)
+            gr.capture_end()
+        bq.use_stream(torch.cuda.current_stream(dev))
+        gr.replay(); torch.cuda.synchronize()
+        tq = sorted(ev_time(gr.replay, 1) for _ in range(5))[2]/k
+    else:
+        tq = sorted(ev_time(lambda: bq.mult(xq, yq), k) for _ in range(3))[1]/k
+    tl = sorted(ev_time(lambda: bq.l2e(xq), 20) for _ in range(3))[1]/20
+    row = {"problem": problem, "p": p, "n": n, "dofs": bq.ndofs, "GDOF/s": bq.ndofs/tq/1e9, "ms_per_step": tq*1e3,
+           "apply_frac": (b1 + b2)/tq/1e9/HBM_PEAK_GBS, "l2e_ms": tl*1e3, "l2e_frac": b1/tl/1e9/HBM_PEAK_GBS,
+           "launch": f"hip graph of {k} applies" if graph else "eager"}
+    if cg_iters > 0:
+        rhs = torch.rand(bq.ndofs, dtype=torch.float64, generator=gen).to(dev)
+        rhs[bq.ess.long()] = 0.0
+        bq.pcg(rhs, 0.0, max_iter=3, check_every=3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, res, _ = bq.pcg(rhs, 0.0, max_iter=cg_iters, check_every=cg_iters)
+        torch.cuda.synchronize()
+        tcg = time.perf_counter() - t0
+        row["cg_dofs_iter_per_s"] = bq.ndofs*res.iterations/tcg
+        row["cg_frac"] = (b1 + b2 + 96*bq.ndofs)*res.iterations/tcg/1e9/HBM_PEAK_GBS
+    del bq, xq, yq
+    torch.cuda.empty_cache()
+    return row
+
+
 def cpu_baseline(problem, p, seconds):
     """The CPU oracle (oracle/pa_oracle.c, the restatement of MFEM's `-d cpu` PA path) on the
-    host cores: the same operator at the same order on a bounded sample (a (64/p)^3 mesh),
-    OpenMP over elements.  kind = "port"."""
+    host cores: the same operator at the same order on a bounded sample -- a mesh of ~1e6 dofs, whose pa_data
+    (160 MB at p = 4) does not fit the host's last-level cache -- OpenMP over elements.  kind = "port"."""
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle_lib as orc
     from mfem_amd.cartesian import CartesianProblem
     from mfem_amd.tables import bakeoff_tables
     kind, D, Q, B, G, Bn, Gn, W = bakeoff_tables(problem, p)
-    n = max(2, 64//p)
+    n = max(2, round(1.0e6**(1.0/3.0)/p))
     prob = CartesianProblem(p, n, n, n)
     ne, ndofs = prob.ne, prob.ndofs
     J = np.zeros(9*Q**3*ne)
@@ -265,7 +310,13 @@ def cpu_baseline(problem, p, seconds):
         el = time.perf_counter() - t0
         if el > seconds:
             break
+    try:
+        import psutil
+        phys, logical = psutil.cpu_count(logical=False), psutil.cpu_count(logical=True)
+    except Exception:                                                        # noqa: BLE001
+        phys, logical = None, os.cpu_count()
     out = {"value": ndofs*reps/el/1e9, "unit": "GDOF/s", "cores": int(orc.lib.orc_num_threads()), "kind": "port",
+           "host_physical_cores": phys, "host_logical_cpus": logical,
            "sample": f"{reps} L->L applies of the same operator (p={p}, Q1D={Q}) on a {n}^3 mesh, {ndofs} dofs, "
                      f"{el:.1f} s, OpenMP over elements"}
     if kind:
@@ -275,7 +326,11 @@ def cpu_baseline(problem, p, seconds):
         opc = orc.Operator(kind, D, Q, ne, ndofs, B, G, pa, prob.gather_map, prob.offsets, prob.indices, ess=ess)
         dinv = orc.jacobi_setup(opc.diag(), ess)
         b = np.ones(ndofs); b[ess] = 0.0
-        its_cap = 20
+        # at least ~1.5 s of Jacobi-PCG: a short first leg sizes the sample
+        t0 = time.perf_counter()
+        opc.pcg(b, dinv, 0.0, max_iter=5)
+        per_it = (time.perf_counter() - t0)/5
+        its_cap = int(min(400, max(20, 1.5/max(per_it, 1e-4))))
         t0 = time.perf_counter()
         _, its, _, _ = opc.pcg(b, dinv, 0.0, max_iter=its_cap)
         elc = time.perf_counter() - t0

@@ -126,10 +126,15 @@ static void run_case(int bp, int p, int N)
    internal::DeviceSync();
    const double t_solve = now() - t0;
    const int its = cg.GetNumIterations();
+   // the stopping margin: (B r, r) one iteration before the stop, at the stop, and the threshold
+   const std::vector<real_t> &h = cg.ResidualHistory();
+   const double nom0 = h.empty() ? 0.0 : h[0], nom_last = h.empty() ? 0.0 : h.back();
+   const double nom_prev = h.size() >= 2 ? h[h.size() - 2] : nom0;
    printf("{\"phase\": \"problem\", \"bp\": %d, \"p\": %d, \"N\": %d, \"dofs\": %d, \"iterations\": %d, \"converged\": %d, "
           "\"norm_X\": %.15e, \"norm_B\": %.15e, \"initial_norm\": %.15e, \"final_norm\": %.15e, \"solve_s\": %.6f, \"MDof_it/s\": %.3f, "
-          "\"hbm_frac\": %.4f}\n",
+          "\"hbm_frac\": %.4f, \"nom0\": %.6e, \"nom_prev\": %.6e, \"nom_last\": %.6e, \"threshold\": %.6e}\n",
           bp, p, N, dofs, its, (int)cg.GetConverged(), X.Norml2(), B.Norml2(), cg.GetInitialNorm(), cg.GetFinalNorm(),
-          t_solve, 1e-6*dofs*its/t_solve, 1e-9*(bytes_apply + 96.0*dofs)*its/t_solve/8000.0);
+          t_solve, 1e-6*dofs*its/t_solve, 1e-9*(bytes_apply + 96.0*dofs)*its/t_solve/8000.0,
+          nom0, nom_prev, nom_last, std::max(nom0*rtol*rtol, 0.0));
    fflush(stdout);
 }

@@ -21,12 +21,15 @@ def _p(t):
 
 
 class BakeoffProblem:
-    def __init__(self, problem, p, n, device, part=None, exchange=None, layout=1):
+    def __init__(self, problem, p, n, device, part=None, exchange=None, layout=1, device_tables=False):
         """`part`: None (serial Cartesian box of n elements), a BoxPartition, or a GeneralPartition of any hex
-        mesh's tables (then n is ignored)."""
+        mesh's tables (then n is ignored).  device_tables: build the E->L table (`offsets`, `indices`) from the
+        gather map on the device (a stable sort by L-dof = the reference's (element, local index) order within a
+        dof, fem/restriction.cpp:86-99) instead of numpy on the host -- the same integers, seconds instead of a
+        minute at 1e8 dofs."""
         self.dev = torch.device(device)
         self.part, self.ex, self.layout = part, exchange, layout
-        self.prob = part.prob if part is not None else CartesianProblem(p, n[0], n[1], n[2])
+        self.prob = part.prob if part is not None else CartesianProblem(p, n[0], n[1], n[2], transpose=not device_tables)
         pr = self.prob
         self.kind, self.D, self.Q, self.B, self.G, Bn, Gn, W = bakeoff_tables(problem, p)
         kind, D, Q = self.kind, self.D, self.Q
@@ -67,7 +70,15 @@ class BakeoffProblem:
             else:
                 self.e_split = 0
         self._nodes_E = nodes_E
-        self.gm, self.off, self.ind = t(gather_map), t(offsets), t(indices)
+        self.gm = t(gather_map)
+        if offsets is None:
+            ind = torch.sort(self.gm, stable=True).indices
+            self.ind = ind.to(torch.int32)
+            del ind
+            self.off = torch.zeros(pr.ndofs + 1, dtype=torch.int32, device=self.dev)
+            self.off[1:] = torch.cumsum(torch.bincount(self.gm, minlength=pr.ndofs), 0).to(torch.int32)
+        else:
+            self.off, self.ind = t(offsets), t(indices)
         nodesE, Wd, one = t(nodes_E), t(W), torch.ones(1, dtype=torch.float64, device=self.dev)
         self.pa = torch.zeros(capi.lib.mfem_amd_pa_data_size(kind, layout, Q, self.ne), dtype=torch.float64, device=self.dev)
         capi.call("mfem_amd_pa_setup_from_nodes_3d", kind, self.Dn, Q, 1, self.ne, Bn, Gn, _p(Wd), _p(nodesE), _p(one), 1,
@@ -101,6 +112,10 @@ class BakeoffProblem:
         self._dinv = None
         self._ws = None
         self._comm = None
+
+    def use_stream(self, stream):
+        """launch on `stream` (a torch stream) from now on -- e.g. a capturing stream for HIP-graph replay"""
+        self.stream = C.c_void_p(stream.cuda_stream)
 
     # ---- BilinearForm::Mult (unconstrained L->L), the BK "Kernel" of bench_ceed.cpp:163-190
     def l2e(self, x, e0=0, e1=None):

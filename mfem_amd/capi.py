@@ -7,7 +7,7 @@ from pathlib import Path
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-_SO = _HERE / "libmfem_amd.so"
+_SO = Path(os.environ.get("MFEM_AMD_LIB", _HERE / "libmfem_amd.so"))     # MFEM_AMD_LIB: a tuning build of the same ABI
 if not _SO.exists():
     raise ImportError(
         f"{_SO} is missing: build the HIP extension first "

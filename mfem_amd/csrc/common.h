@@ -24,6 +24,18 @@ struct BasisT
    double g[N];
 };
 
+// The same with the transposed tables bt[d*Q + q], gt[d*Q + q] beside them (the specialised apply kernels:
+// D*Q <= 90, 2880 B of the 4 KB kernel-argument segment): a contraction phase whose unrolled loops walk q
+// fastest reads contiguous scalar runs too -- with strided scalar operands the (9,Q) kernels ran out of SGPRs.
+template <int N>
+struct BasisTT
+{
+   double b[N];
+   double g[N];
+   double bt[N];
+   double gt[N];
+};
+
 // Elements per workgroup of the specialised apply kernels (Q*Q*NBZ ~ 200..256 threads; Q = 8: two
 // one-wave elements -- measured 6 % faster than four for the collocated and vector kernels, equal
 // otherwise; halving the other sizes was equal or slower, profiles/r1/sweep_nbz_half.txt).

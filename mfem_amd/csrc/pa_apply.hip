@@ -72,6 +72,33 @@ constexpr int minw_for(int KIND, int D, int PF = 0)
 #ifndef MFA_WAVE_SYNC
 #define MFA_WAVE_SYNC 1
 #endif
+// tuning builds: -DMFA_ONLY_D=<D1D> compiles the specialisations of one D1D only (seconds instead of minutes)
+#ifndef MFA_ONLY_D
+#define MFA_ONLY_D 0
+#endif
+// pa_data is read exactly once per application; where it measured faster (profiles/r2/nt_probe.txt: mass p >= 5
+// 4-7 %, collocated diffusion p = 1, 3 4-5 %, BP3 p = 6 3 %; 1-2.5 % slower for BP3 p <= 4) it is loaded with the
+// non-temporal policy, which keeps the L2 for the gathered x values.  MFA_NT=0|1 forces it off / on (tuning builds).
+constexpr bool nt_table(int KIND, int D, int Q)
+{
+#ifdef MFA_NT
+   return MFA_NT != 0;
+#else
+   return KIND == 0 ? D >= 6 : ((Q == D && D <= 4) || (Q > D && D == 7));
+#endif
+}
+template <bool NT> __device__ __forceinline__ double load_pa(const double *p)
+{
+   return NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <bool NT> __device__ __forceinline__ double2 load_pa(const double2 *p)
+{
+   if (!NT) { return *p; }
+   typedef double v2d __attribute__((ext_vector_type(2)));
+   const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p));
+   double2 r; r.x = v.x; r.y = v.y;
+   return r;
+}
 template <bool WS>
 __device__ __forceinline__ void phase_sync()
 {
@@ -101,7 +128,7 @@ __device__ __forceinline__ void phase_sync()
 // stores and reads vd identical copies.  E-vectors are (D,D,D,vd,NE) as in the reference.
 template <int KIND, int D, int Q, int NBZ, bool GATHER, bool ACCUM, bool BLK = false, int ABL = 0, bool PERSIST = true, int PF = 0, int RB = 0, bool VEC = false>
 __global__ void __launch_bounds__(Q*Q*NBZ, minw_for(KIND, D, PF)) MFA_VGPR_CAP
-k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const BasisT<D*Q> bg,
+k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const BasisTT<D*Q> bg,
            const double *__restrict__ Dq, const double *__restrict__ x,
            const int *__restrict__ gmap, double *__restrict__ yE, const VecArgs va)
 {
@@ -247,7 +274,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
 #pragma unroll
                for (int cp = 0; cp < 3; cp++)
                {
-                  const double2 v = Db[(qz*3 + cp)*(NBZ*QQ)];
+                  const double2 v = load_pa<nt_table(KIND, D, Q)>(&Db[(qz*3 + cp)*(NBZ*QQ)]);
                   O[qz][(2*cp) % NC] = v.x; O[qz][(2*cp + 1) % NC] = v.y;
                }
             }
@@ -256,7 +283,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
          {
             const double *Db = Dq + (VEC ? comp*va.d_comp_stride : 0) + bt*(int64_t)(Q*NBZ*QQ) + tz*QQ + b*Q + a;
 #pragma unroll
-            for (int qz = 0; qz < Q; qz++) { if (qz >= qz0 && qz < qz1) { O[qz][0] = Db[qz*(NBZ*QQ)]; } }
+            for (int qz = 0; qz < Q; qz++) { if (qz >= qz0 && qz < qz1) { O[qz][0] = load_pa<nt_table(KIND, D, Q)>(&Db[qz*(NBZ*QQ)]); } }
          }
          return;
       }
@@ -661,8 +688,9 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
 #pragma unroll
                   for (int qx = 0; qx < Q; qx++)
                   {
-                     y += RBB(b, B, qx*D + dx, zt)*V23[qx];
-                     if (KIND) { y += RBB(g, G, qx*D + dx, zt)*V1[qx]; }
+                     // transposed tables: this phase walks q fastest, and scalar operands want contiguous runs
+                     y += RBB(bt, B, dx*Q + qx, zt)*V23[qx];
+                     if (KIND) { y += RBB(gt, G, dx*Q + qx, zt)*V1[qx]; }
                   }
                   yv[dx] = y;
                }
@@ -891,8 +919,8 @@ k_pa_apply_generic(const int D, const int Q, const int64_t ne, const BasisT<MAX_
 // (fem/kernel_dispatch.hpp:131-181).  Registered: D1D = 2..9 with Q1D in {D1D, D1D+1}
 // (BP5 collocated GLL and BP1/BP3/ex1 Gauss-Legendre p+2), i.e. p = 1..8.
 // ------------------------------------------------------------------------------------
-template <int N>
-static void fill_basis(BasisT<N> &bg, int D, int Q, const double *B, const double *G)
+template <class BG>
+static void fill_basis(BG &bg, int D, int Q, const double *B, const double *G)
 {
    for (int q = 0; q < Q; q++)
    {
@@ -900,6 +928,18 @@ static void fill_basis(BasisT<N> &bg, int D, int Q, const double *B, const doubl
       {
          bg.b[q*D + d] = B[q + Q*d];
          bg.g[q*D + d] = G ? G[q + Q*d] : 0.0;
+      }
+   }
+}
+template <int N>
+static void fill_basis(BasisTT<N> &bg, int D, int Q, const double *B, const double *G)
+{
+   for (int q = 0; q < Q; q++)
+   {
+      for (int d = 0; d < D; d++)
+      {
+         bg.b[q*D + d] = bg.bt[d*Q + q] = B[q + Q*d];
+         bg.g[q*D + d] = bg.gt[d*Q + q] = G ? G[q + Q*d] : 0.0;
       }
    }
 }
@@ -1010,7 +1050,7 @@ static int launch_apply(int64_t ne, const double *B, const double *G, const doub
       if (per_cu < 1) { per_cu = 1; }
       resident[dev] = per_cu*cus;
    }
-   BasisT<D*Q> bg;
+   BasisTT<D*Q> bg;
    fill_basis(bg, D, Q, B, G);
    const int64_t nb = (ne + NBZ - 1)/NBZ;
    if (nb == 0) { return 0; }
@@ -1033,7 +1073,7 @@ template <int KIND, bool GATHER, bool ACCUM, bool BLK>
 static apply_fn find_apply(int D, int Q)
 {
 #define MFA_CASE(DD, QQ) \
-   if (D == DD && Q == QQ) { return launch_apply<KIND, DD, QQ, GATHER, ACCUM, BLK>; }
+   if constexpr (MFA_ONLY_D == 0 || DD == MFA_ONLY_D) { if (D == DD && Q == QQ) { return launch_apply<KIND, DD, QQ, GATHER, ACCUM, BLK>; } }
    MFA_CASE(2, 2) MFA_CASE(2, 3) MFA_CASE(3, 3) MFA_CASE(3, 4) MFA_CASE(4, 4) MFA_CASE(4, 5)
    MFA_CASE(5, 5) MFA_CASE(5, 6) MFA_CASE(6, 6) MFA_CASE(6, 7) MFA_CASE(7, 7) MFA_CASE(7, 8)
    MFA_CASE(8, 8) MFA_CASE(8, 9) MFA_CASE(9, 9) MFA_CASE(9, 10)
@@ -1111,7 +1151,7 @@ static int launch_apply_vec(int64_t ne, const double *B, const double *G, const 
    constexpr int NBZ = nbz_for(Q);
    constexpr int RBV = Q > 3 ? rb_table(KIND, D, Q) : 0;
    auto kern = k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM, BLK, 0, false, 0, RBV, true>;
-   BasisT<D*Q> bg;
+   BasisTT<D*Q> bg;
    fill_basis(bg, D, Q, B, G);
    const int64_t nb = (ne + NBZ - 1)/NBZ;
    if (nb == 0) { return 0; }
@@ -1125,7 +1165,7 @@ template <int KIND, bool GATHER, bool ACCUM, bool BLK>
 static apply_vec_fn find_apply_vec(int D, int Q)
 {
 #define MFA_CASE(DD, QQ) \
-   if (D == DD && Q == QQ) { return launch_apply_vec<KIND, DD, QQ, GATHER, ACCUM, BLK>; }
+   if constexpr (MFA_ONLY_D == 0 || DD == MFA_ONLY_D) { if (D == DD && Q == QQ) { return launch_apply_vec<KIND, DD, QQ, GATHER, ACCUM, BLK>; } }
    MFA_CASE(2, 2) MFA_CASE(2, 3) MFA_CASE(3, 3) MFA_CASE(3, 4) MFA_CASE(4, 4) MFA_CASE(4, 5)
    MFA_CASE(5, 5) MFA_CASE(5, 6) MFA_CASE(6, 6) MFA_CASE(6, 7) MFA_CASE(7, 7) MFA_CASE(7, 8)
    MFA_CASE(8, 8) MFA_CASE(8, 9) MFA_CASE(9, 9) MFA_CASE(9, 10)

@@ -325,9 +325,21 @@ class Exchange:
             v[self.ext_ldof.long()] = 0.0
 
     # -- transport -------------------------------------------------------------------
+    def _stream_ctx(self, stream):
+        """Everything the transport issues (collectives, staging copies) is ordered on the hipStream_t the caller
+        handed over -- the contract of mfem_amd_comm (include/mfem_amd.h): `stream` may differ from torch's
+        current stream.  None / the null pointer = the stream torch is on."""
+        import contextlib
+        ptr = stream.value if isinstance(stream, C.c_void_p) else stream
+        if not self.on_gpu or not ptr:
+            return contextlib.nullcontext()
+        return torch.cuda.stream(torch.cuda.ExternalStream(int(ptr), device=self.device))
+
     def _transfer(self, send_buf, send_list, send_sizes, recv_buf, recv_list, recv_sizes, send_host=None, recv_host=None):
-        if not send_list and not recv_list:
-            return
+        alone = not dist.is_initialized() or dist.get_world_size(self.group) == 1
+        if not send_list and not recv_list and (alone or not self.use_alltoall):
+            return          # point-to-point: nothing to post.  The all-to-all is a collective: every rank calls it,
+                            # with all-zero splits if it has no neighbour (a rank that skipped it would hang the others)
         if self.stage:
             torch.cuda.current_stream().synchronize()
             send_host.copy_(send_buf)
@@ -376,26 +388,29 @@ class Exchange:
         """P: ghost entries of v := owner values.  v: tensor or raw device pointer."""
         p = self.part
         self._pack(self.shr_ltdof, v, self.shr_buf, stream)
-        self._transfer(self.shr_buf, p.upper, p.shr_sizes, self.ext_buf, p.lower, p.ext_sizes,
-                       getattr(self, "shr_host", None), getattr(self, "ext_host", None))
+        with self._stream_ctx(stream):
+            self._transfer(self.shr_buf, p.upper, p.shr_sizes, self.ext_buf, p.lower, p.ext_sizes,
+                           getattr(self, "shr_host", None), getattr(self, "ext_host", None))
         self._unpack(self.ext_ldof, self.ext_buf, v, stream)
 
     def reverse(self, v, stream=None):
         """P^T: owners += ghost contributions (fixed neighbour order); ghosts := 0."""
         p = self.part
         self._pack(self.ext_ldof, v, self.ext_buf, stream)
-        self._transfer(self.ext_buf, p.lower, p.ext_sizes, self.shr_buf, p.upper, p.shr_sizes,
-                       getattr(self, "ext_host", None), getattr(self, "shr_host", None))
+        with self._stream_ctx(stream):
+            self._transfer(self.ext_buf, p.lower, p.ext_sizes, self.shr_buf, p.upper, p.shr_sizes,
+                           getattr(self, "ext_host", None), getattr(self, "shr_host", None))
         self._accumulate(v, stream)
         self._zero_ghosts(v, stream)
 
-    def allreduce_sum(self, t):
-        if self.stage:
-            h = t.cpu()
-            dist.all_reduce(h, group=self.group)
-            t.copy_(h)
-        else:
-            dist.all_reduce(t, group=self.group)
+    def allreduce_sum(self, t, stream=None):
+        with self._stream_ctx(stream):
+            if self.stage:
+                h = t.cpu()                          # synchronises the (now current) stream
+                dist.all_reduce(h, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, group=self.group)
 
     # -- the C ABI communicator ---------------------------------------------------------
     def make_comm(self, workspace):
@@ -415,12 +430,14 @@ class Exchange:
                     return 1
             return w
 
+        self._sum_views = {}       # views into THIS workspace only (an earlier, re-allocated one must never be reduced)
+
         def allreduce(ctx, buf, n, stream):
             off = buf - workspace.data_ptr()
             key = (off, n)
             if key not in self._sum_views:
                 self._sum_views[key] = workspace[off:off + 8*n].view(torch.float64)
-            self.allreduce_sum(self._sum_views[key])
+            self.allreduce_sum(self._sum_views[key], C.c_void_p(stream))
 
         cbs = (AR(guard(allreduce)), EX(guard(lambda ctx, v, s: self.forward(v, C.c_void_p(s)))),
                EX(guard(lambda ctx, v, s: self.reverse(v, C.c_void_p(s)))))

@@ -13,6 +13,22 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 ANCH = json.loads((Path(__file__).parent / "golden" / "baseline_anchors.json").read_text())
+# Stopping margins recorded on MI355X (tools/pcg_margins.py): the cases whose device iteration count differs from the
+# reference's at rel tol 1e-12, with (B r, r) around the stop.  Every other case must reproduce the count exactly.
+MARGINS = json.loads((Path(__file__).parent / "golden" / "pcg_margins.json").read_text())
+DIFFER = {(d["driver"], d["problem"], d["p"]): d["delta"] for d in MARGINS["differ"]}
+
+
+def check_iterations(driver, problem, p, its, ref_its, nom0, nom_before):
+    """identical CG iteration count (linalg/solvers.cpp:919,988), except in the recorded cases, where the stopping
+    decision provably sits in the rounding floor: (B r, r) one step before the earlier stop is already 22 orders
+    below (B r, r)_0, and the difference does not exceed the recorded one."""
+    key = (driver, problem, p)
+    if key not in DIFFER:
+        assert its == ref_its, (key, its, ref_its)
+        return
+    assert nom_before < 1e-22*nom0, (key, nom_before, nom0)
+    assert abs(its - ref_its) <= abs(DIFFER[key]), (key, its, ref_its, DIFFER[key])
 
 
 @pytest.mark.parametrize("case", ANCH["cases"], ids=lambda c: f"{c['problem']}_p{c['p']}")
@@ -30,16 +46,13 @@ def test_bakeoff_known_answers(case):
     nX = float(torch.linalg.vector_norm(X).item())
     # ||X|| : 1e-10 relative (CG at rel tol 1e-12 leaves an error of that order)
     assert abs(nX - case["norm_X"]) < 1e-9*case["norm_X"], (nX, case["norm_X"])
-    # Iteration count at THIS tolerance (rel 1e-12 on sqrt((Br,r)), i.e. a 1e-24 reduction of
-    # (Br,r)) is decided inside the rounding-noise floor of double-precision CG: the last
-    # residuals are ~1e-28 and depend on the summation order of the dot products (the
-    # reference sums sequentially on one core, general/reducers.hpp:589-592).  Equal counts
-    # are required unless the run is provably in that regime; then +-1 (or a stagnation
-    # plateau, <= 10 %) is accepted.  Exact equality at ex1's tolerance is asserted against
-    # the oracle in test_iteration_count_equals_oracle below.
-    if res.iterations != case["pcg_its"]:
-        assert hist[min(res.iterations, case["pcg_its"]) - 1] < 1e-22*hist[0]
-        assert abs(res.iterations - case["pcg_its"]) <= max(1, case["pcg_its"]//10), (res.iterations, case["pcg_its"])
+    # Iteration count at THIS tolerance (rel 1e-12 on sqrt((Br,r)), i.e. a 1e-24 reduction of (Br,r)): equal to the
+    # reference's, except in the cases recorded in tests/golden/pcg_margins.json, where the last residuals (~1e-28)
+    # depend on the summation order of the dot products (the reference sums sequentially on one core,
+    # general/reducers.hpp:589-592).  Exact equality at ex1's tolerance is asserted against the oracle in
+    # test_iteration_count_equals_oracle below.
+    k = min(res.iterations, case["pcg_its"])
+    check_iterations("python", case["problem"], p, res.iterations, case["pcg_its"], hist[0], hist[k - 1])
     assert res.converged == 1
 
 
@@ -194,5 +207,5 @@ def test_vector_bakeoff_known_answers(case):
     nX = float(torch.linalg.vector_norm(X).item())
     assert abs(nX - case["norm_X"]) < 1e-8*case["norm_X"], (nX, case["norm_X"])
     assert res.converged == 1
-    # rel tol 1e-12: the last decision sits in rounding noise (see test_bakeoff_known_answers)
-    assert abs(res.iterations - case["pcg_its"]) <= max(1, case["pcg_its"]//10), (res.iterations, case["pcg_its"])
+    k = min(res.iterations, case["pcg_its"])
+    check_iterations("python", case["problem"], p, res.iterations, case["pcg_its"], hist[0], hist[k - 1])

@@ -1,6 +1,7 @@
 """-m gpu: the partitioned solve through the C ABI (mfem_amd_pcg_pa_par + the exchange of
 mfem_amd/parallel.py), 2 ranks sharing cuda:0 over gloo (host-staged messages), against the
-serial device solve of the same global problem: identical iteration count, solution to 1e-10."""
+serial device solve of the same global problem AND against the CPU oracle on the global problem:
+identical iteration count, solution to 1e-10, operator action to 1e-12."""
 import os
 import sys
 from pathlib import Path
@@ -71,6 +72,65 @@ def _worker(rank, world, port, problem, p, n, out, mode="box"):
         own = ~ghost_mask
         e2 = np.max(np.abs(yl.cpu().numpy()[own] - ys.cpu().numpy()[l2g][own]))/float(ys.abs().max())
         assert e2 < 1e-12, e2
+        if mode == "box" and vd == 1:
+            # ---- the same two-rank device results against the CPU ORACLE on the global problem (not only against
+            # the serial device solve): operator action to 1e-12, Jacobi-PCG iteration count equal, X to 1e-10
+            sys.path.insert(0, str(ROOT / "tests"))
+            import oracle_lib as orc
+            from mfem_amd.tables import bakeoff_tables
+            kind, D, Q, B, G, Bn, Gn, W = bakeoff_tables(problem, p)
+            gp, gne = sp.prob, sp.ne
+            J = np.zeros(9*Q**3*gne)
+            orc.lib.orc_jacobians_3d(2, Q, gne, Bn, Gn, gp.nodes_E, J)
+            det = np.zeros(Q**3*gne); orc.lib.orc_det_3d(Q, gne, J, det)
+            if kind:
+                pa = np.zeros(6*Q**3*gne); orc.lib.orc_diffusion_setup_3d(Q, 1, gne, W, J, np.ones(1), 1, pa)
+            else:
+                pa = np.zeros(Q**3*gne); orc.lib.orc_mass_setup_3d(Q, gne, W, det, np.ones(1), 1, pa)
+            gop = orc.Operator(kind, D, Q, gne, gp.ndofs, B, G, pa, gp.gather_map, gp.offsets, gp.indices, sp.ess_host)
+            yo = orc.Operator(kind, D, Q, gne, gp.ndofs, B, G, pa, gp.gather_map, gp.offsets, gp.indices).mult(xg.cpu().numpy())
+            e3 = np.max(np.abs(yl.cpu().numpy()[own] - yo[l2g][own]))/np.max(np.abs(yo))
+            assert e3 < 1e-12, e3
+            bE = np.zeros(gne*D**3); orc.lib.orc_domain_lf_3d(D, Q, gne, B, W, det, 1.0, bE)
+            bo = np.zeros(gp.ndofs); orc.lib.orc_restriction_mult_transpose(gp.ndofs, gp.offsets, gp.indices, bE, bo, 0, 0)
+            bo[sp.ess_host] = 0.0
+            # iteration count at ex1's stopping rule (rel tol 1e-6 on sqrt((B r, r)), examples/ex1.cpp:251), where the
+            # CG recurrences of the two implementations still agree to rounding; far below that the residual
+            # histories of a fast-converging solve drift apart by O(1) factors (loss of orthogonality amplifies the
+            # dot-product order), so at 1e-10 the SOLUTIONS are compared, not the counts
+            dinv_o = orc.jacobi_setup(gop.diag(), sp.ess_host)
+            Xo6, its_o6, ho6, conv_o6 = gop.pcg(bo, dinv_o, 1e-6, max_iter=1000)
+            X6, res6, hist6 = bp.pcg(b, 1e-6, max_iter=1000, check_every=4, want_hist=True)
+            assert res6.iterations == its_o6 and conv_o6 and res6.converged == 1, (res6.iterations, its_o6, hist6[-3:], ho6[-3:])
+            assert np.max(np.abs(hist6 - ho6)/ho6) < 1e-6, np.max(np.abs(hist6 - ho6)/ho6)
+            Xo, its_o, ho, conv_o = gop.pcg(bo, dinv_o, 1e-10, max_iter=1000)
+            assert conv_o and abs(res.iterations - its_o) <= 2, (res.iterations, its_o)
+            eo = np.max(np.abs(X.cpu().numpy() - Xo[l2g]))/np.max(np.abs(Xo))
+            assert eo < 1e-9, eo
+            nX = float(np.sqrt(np.sum(X.cpu().numpy()[own]**2)))
+            # ---- the all-reduce slot follows the workspace: small, large, small max_iter (the workspace is
+            # re-allocated when max_iter grows and the history block moves the slot)
+            for mi in (10, 40, 10):
+                Xa, ra, _ = bp.pcg(b, 0.0, max_iter=mi, check_every=5)
+                Xb, rb, _ = sp.pcg(sp.rhs_unit_source(), 0.0, max_iter=mi, check_every=5)
+                torch.cuda.synchronize()
+                assert ra.iterations == rb.iterations == mi
+                ea = np.max(np.abs(Xa.cpu().numpy() - Xb.cpu().numpy()[l2g]))/float(Xb.abs().max())
+                assert ea < 1e-10, (mi, ea)
+                if rb.final_nom > 1e-16*rb.initial_nom:          # below that (B r, r) is rounding noise
+                    assert abs(ra.final_nom - rb.final_nom) <= 1e-6*abs(rb.final_nom), (mi, ra.final_nom, rb.final_nom)
+            # ---- stream contract of the comm callbacks: the exchange on a stream that is NOT torch's current one
+            import ctypes as C
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                big = torch.rand(1 << 24, dtype=torch.float64, device="cuda:0")
+                for _ in range(4):
+                    big = big*1.0000001 + 1e-9                      # keeps `side` busy ahead of the fill below
+                v = xg[torch.from_numpy(l2g).cuda()].clone()
+                v[bp.ghost.long()] = -777.0
+            ex.forward(v.data_ptr(), C.c_void_p(side.cuda_stream))   # current stream: the default one
+            side.synchronize()
+            assert torch.equal(v.cpu(), xg.cpu()[torch.from_numpy(l2g)])
         out.put((rank, "ok"))
     except Exception:                                                        # noqa: BLE001
         import traceback
@@ -182,3 +242,104 @@ def test_rccl_backend_world_of_one():
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", _NCCL_ONE], capture_output=True, text=True, timeout=280, env=env, cwd=str(ROOT))
     assert r.returncode == 0 and "nccl-one ok" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
+
+
+# ---- the C++ transport (libmfem_amd_comm.so): no torch.distributed, no Python inside the PCG iteration ----------
+def _native_worker(rank, world, port, problem, p, n, out, mode, transport):
+    sys.path.insert(0, str(ROOT))
+    try:
+        import torch
+        from mfem_amd import capi
+        from mfem_amd.bp import BakeoffProblem
+        from mfem_amd.comm import NativeExchange, World
+        from mfem_amd.parallel import BoxPartition, GeneralPartition, MeshTables, process_grid
+        torch.cuda.set_device(0)
+        capi.call("mfem_amd_init", 0)
+        w = World(rank, world, "127.0.0.1", port, 0, transport)
+        assert (w.rank, w.size, w.transport) == (rank, world, transport)
+        pg = process_grid(world)
+        if mode == "box":
+            part = BoxPartition(p, (n, n, n), pg, rank)
+        else:
+            from mfem_amd.cartesian import CartesianProblem
+            tabs = MeshTables.from_cartesian(CartesianProblem(p, 2*n, n, n + 1))
+            pv = np.random.default_rng(5).integers(0, world, tabs.ne).astype(np.int32)
+            part = GeneralPartition(tabs, pv, rank)
+        vd = 3 if problem in ("bp2", "bp4", "bp6") else 1
+        ex = NativeExchange(w, part, "cuda:0", vdim=vd if vd > 1 else 0)
+        bp = BakeoffProblem(problem, p, (n, n, n), "cuda:0", part=part, exchange=ex)
+        n_global = int(w.allreduce_host([part.n_owned*vd])[0])
+        b = bp.rhs_unit_source()
+        X, res, hist = bp.pcg(b, 1e-10, max_iter=1000, check_every=4, want_hist=True)
+        if mode == "box":
+            sp = BakeoffProblem(problem, p, (pg[0]*n, pg[1]*n, pg[2]*n), "cuda:0")
+        else:
+            sp = BakeoffProblem(problem, p, None, "cuda:0", part=GeneralPartition(tabs, np.zeros(tabs.ne, np.int32), 0))
+        assert n_global == sp.ndofs, (n_global, sp.ndofs)
+        Xs, rs, hs = sp.pcg(sp.rhs_unit_source(), 1e-10, max_iter=1000, check_every=4, want_hist=True)
+        torch.cuda.synchronize()
+        l2g, _ = part.local_to_global()
+        ghost_mask = part.ghost
+        if vd > 1:
+            l2g = (np.asarray(l2g, np.int64)[:, None]*vd + np.arange(vd)[None, :]).reshape(-1)
+            ghost_mask = np.repeat(part.ghost, vd)
+        assert res.iterations == rs.iterations and res.converged == 1, (res.iterations, rs.iterations)
+        Xs_l = Xs.cpu().numpy()[l2g]
+        assert np.max(np.abs(X.cpu().numpy() - Xs_l))/np.max(np.abs(Xs_l)) < 1e-10
+        big = hs > 1e-12*hs[0]
+        assert np.max(np.abs(hist[big] - hs[big])/hs[big]) < 1e-6
+        xg = torch.rand(sp.ndofs, dtype=torch.float64, generator=torch.Generator().manual_seed(1)).cuda()
+        ys = torch.empty_like(xg); sp.mult(xg, ys)
+        xl = xg[torch.from_numpy(l2g).cuda()].clone()
+        xl[bp.ghost.long()] = 0.0
+        yl = torch.empty_like(xl); bp.mult(xl, yl)
+        # the callbacks honour a stream that is not torch's current one
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            v = xg[torch.from_numpy(l2g).cuda()].clone()
+            v[bp.ghost.long()] = -777.0
+        import ctypes as C
+        ex.forward(v.data_ptr(), C.c_void_p(side.cuda_stream))
+        side.synchronize()
+        torch.cuda.synchronize()
+        assert torch.equal(v.cpu(), xg.cpu()[torch.from_numpy(l2g)])
+        own = ~ghost_mask
+        e2 = np.max(np.abs(yl.cpu().numpy()[own] - ys.cpu().numpy()[l2g][own]))/float(ys.abs().max())
+        assert e2 < 1e-12, e2
+        assert float(yl[bp.ghost.long()].abs().max()) == 0.0 if bp.ghost.numel() else True
+        w.barrier()
+        ex.close(); w.close()
+        out.put((rank, "ok"))
+    except Exception:                                                        # noqa: BLE001
+        import traceback
+        out.put((rank, traceback.format_exc()))
+
+
+def _run_native(world, problem, p, n, mode, transport):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 30100 + (os.getpid() % 1000) + 11*len(mode) + 3*world
+    procs = [ctx.Process(target=_native_worker, args=(r, world, port, problem, p, n, out, mode, transport)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = [out.get(timeout=150) for _ in range(world)]
+    for pr in procs:
+        pr.join(30)
+    bad = [m for _, m in res if m != "ok"]
+    assert not bad, bad[0]
+
+
+@pytest.mark.parametrize("world,problem,p,n,mode", [(2, "bp3", 3, 4, "box"), (2, "bp1", 2, 5, "box"), (3, "bp3", 2, 3, "random"),
+                                                    (4, "bp3", 2, 3, "box"), (2, "bp4", 2, 3, "box")])
+def test_cxx_transport_ranks_on_one_gpu_match_serial(world, problem, p, n, mode):
+    """libmfem_amd_comm.so with the host-staged TCP transport (RCCL refuses two ranks on one device): the exchange
+    tables, message order, deterministic accumulate and all-reduce of the C++ communicator, driven from
+    mfem_amd_pcg_pa_par with C callbacks, against the serial device solve."""
+    _run_native(world, problem, p, n, mode, 1)
+
+
+def test_cxx_transport_rccl_world_of_one():
+    """The same library on RCCL (ncclCommInitRank, ncclAllReduce on the launch stream) with the only world one GPU
+    allows; eight-GPU runs are the driver's."""
+    _run_native(1, "bp3", 3, 5, "box", 0)

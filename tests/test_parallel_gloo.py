@@ -180,3 +180,57 @@ def test_box_partition_tables():
         assert len(part.upper) == len(part.lower) or True
         assert part.unq_shr_i[-1] == len(part.shr_ltdof)
     assert total == (2*2*2 + 1)**3
+
+
+def _idle_rank_worker(rank, world, port, out):
+    """world of 3, partition over ranks {0, 1} only: rank 2 owns nothing and has no neighbour."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from types import SimpleNamespace
+        from mfem_amd.cartesian import CartesianProblem
+        from mfem_amd.parallel import Exchange, GeneralPartition, MeshTables, chunk_partition
+        from conftest import splitmix
+        tabs = MeshTables.from_cartesian(CartesianProblem(2, 4, 2, 2))
+        pv = chunk_partition(tabs.ne, 2)
+        if rank < 2:
+            part = GeneralPartition(tabs, pv, rank)
+        else:
+            e = np.zeros(0, np.int32)
+            part = SimpleNamespace(upper=[], lower=[], shr_ltdof=e, ext_ldof=e, unq_ltdof=e, unq_shr_i=np.zeros(1, np.int32),
+                                   unq_shr_j=e, shr_sizes=[], ext_sizes=[])
+        ex = Exchange(part, "cpu")
+        assert ex.use_alltoall
+        xg = splitmix(11, tabs.ndofs)
+        if rank < 2:
+            l2g, _ = part.local_to_global()
+            v = torch.from_numpy(np.where(part.ghost, -777.0, xg[l2g]))
+        else:
+            v = torch.zeros(0, dtype=torch.float64)
+        ex.forward(v)                       # a collective: the idle rank must take part (all-zero splits)
+        if rank < 2:
+            assert np.array_equal(v.numpy(), xg[l2g])
+        w = v.clone()
+        ex.reverse(w)
+        if rank < 2:
+            assert np.all(w.numpy()[part.ghost] == 0.0)
+        out.put((rank, "ok"))
+    except Exception:                                                        # noqa: BLE001
+        import traceback
+        out.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank_without_neighbours_takes_part_in_the_all_to_all():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 29300 + (os.getpid() % 1500)
+    procs = [ctx.Process(target=_idle_rank_worker, args=(r, 3, port, out)) for r in range(3)]
+    for pr in procs:
+        pr.start()
+    res = [out.get(timeout=120) for _ in range(3)]
+    for pr in procs:
+        pr.join(30)
+    bad = [m for _, m in res if m != "ok"]
+    assert not bad, bad[0]

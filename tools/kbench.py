@@ -3,6 +3,7 @@
 one (problem, p, n) with HIP events; one line per case.  Used under rocprofv3 --pmc too."""
 import argparse
 import ctypes as C
+import os
 import sys
 from pathlib import Path
 
@@ -58,6 +59,10 @@ def run(problem, p, n, steps, which, layout=1, vdim=0, byvdim=1):
             capi.call("mfem_amd_restrict_scatter", ndofs, ptr(off), ptr(ind), ptr(yE), ptr(y), 0, 0, None)
 
     def timed(fn, k):
+        import gc
+        if os.environ.get("KBENCH_GC", "1") != "0":
+            gc.collect()                  # tensors of the previous case that sit in reference cycles are freed NOW,
+            torch.cuda.synchronize()      # not by a collection in the middle of the timed launches
         for _ in range(3):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -68,7 +73,6 @@ def run(problem, p, n, steps, which, layout=1, vdim=0, byvdim=1):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1)*1e-3/k
 
-    import os
     if os.environ.get("KBENCH_PTRS"):
         print("   ptrs pa=%x x=%x yE=%x gm=%x" % (pa.data_ptr(), x.data_ptr(), yE.data_ptr(), gm.data_ptr()), flush=True)
     b1, b2 = bench.algorithmic_bytes(kind, D, Q, ne, ndofs)
