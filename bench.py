@@ -89,12 +89,13 @@ def main():
     if world > 1:
         part = BoxPartition(p, (n, n, n), pg, rank)
         vd = 3 if args.problem in ("bp2", "bp4", "bp6") else 1
-        ex = Exchange(part, dev, vdim=vd if vd > 1 else 0)
+        ex, transport = make_exchange(part, dev, vd if vd > 1 else 0, rank, world)
         bp = BakeoffProblem(args.problem, p, (n, n, n), dev, part=part, exchange=ex)
         owned = torch.tensor([part.n_owned*vd], dtype=torch.float64, device=dev)
         dist.all_reduce(owned)
         total_dofs = int(owned.item())
     else:
+        transport = None
         bp = BakeoffProblem(args.problem, p, (n, n, n), dev)
         total_dofs = bp.ndofs
     torch.cuda.synchronize()
@@ -208,13 +209,51 @@ def main():
                "config": {"workload": f"CEED {args.problem.upper()} PA operator apply (L->L, P^T A P across GPUs), H1 p={p} "
                                       f"D1D={D} Q1D={Q}, Cartesian hex mesh {n}^3 per GPU",
                           "elements_per_gpu": ne, "local_dofs_per_gpu": ndofs, "global_dofs": total_dofs,
-                          "process_grid": list(pg)},
+                          "process_grid": list(pg), "transport": transport},
                "roofline": roof, "roofline_apply": roof_apply, "cg": cg, "by_order": by_order, "by_size": by_size,
                "cpu_baseline": cpu,
                "setup_s": setup_s}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def make_exchange(part, dev, vdim, rank, world):
+    """The shared-dof exchange of a rank: the C++ RCCL transport (libmfem_amd_comm.so: ncclSend/ncclRecv/ncclAllReduce
+    issued from C callbacks, nothing of a PCG iteration in the interpreter), checked here against the
+    torch.distributed transport on one forward and one reverse exchange; all ranks fall back to the latter together if
+    any of them could not set the former up (MFEM_AMD_BENCH_TRANSPORT=torch forces it)."""
+    import torch
+    import torch.distributed as dist
+    from mfem_amd.parallel import Exchange
+    ex_t = Exchange(part, dev, vdim=vdim)
+    native, why = None, ""
+    mode = os.environ.get("MFEM_AMD_BENCH_TRANSPORT", "native")      # "native-tcp": rehearsal of ranks sharing one GPU
+    if mode != "torch" and (dist.get_backend() == "nccl" or mode == "native-tcp"):
+        try:
+            from mfem_amd.comm import NativeExchange, World
+            w = World(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")), 23,
+                      1 if mode == "native-tcp" else 0)
+            native = NativeExchange(w, part, dev, vdim=vdim)
+            nloc = part.prob.ndofs*max(1, vdim)
+            g = torch.Generator(device="cpu"); g.manual_seed(77 + rank)
+            v1 = torch.rand(nloc, dtype=torch.float64, generator=g).to(dev)
+            ghost = torch.from_numpy(native.part.ext_ldof.astype("int64")).to(dev)
+            v1[ghost] = 0.0
+            v2 = v1.clone()
+            native.forward(v1); ex_t.forward(v2)
+            same = bool(torch.equal(v1, v2))
+            native.reverse(v1); ex_t.reverse(v2)
+            torch.cuda.synchronize()
+            if not (same and bool(torch.equal(v1, v2))):
+                raise RuntimeError("native and torch.distributed exchanges disagree")
+        except Exception as e:                                               # noqa: BLE001
+            native, why = None, f"{type(e).__name__}: {e}"
+    ok = torch.tensor([1.0 if native is not None else 0.0], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if ok.item() > 0:
+        return native, ("host-staged TCP (rehearsal)" if mode == "native-tcp" else "RCCL") + " from C++ (libmfem_amd_comm.so), checked against torch.distributed"
+    return ex_t, "torch.distributed all_to_all_single (RCCL)" + (f"; native transport not used: {why}" if why else "")
 
 
 def size_row(problem, p, dofs, dev, gen, cg_iters=20):

@@ -31,6 +31,9 @@ typedef struct mfem_amd_exchange mfem_amd_exchange; /* one space's shared-dof ex
 
 enum { MFEM_AMD_TRANSPORT_RCCL = 0, MFEM_AMD_TRANSPORT_TCP = 1 };
 
+/* Last error message of the calling thread for the functions of this header (never NULL). */
+const char *mfem_amd_comm_last_error(void);
+
 /* Mpi::Init.  rank < 0: take rank / size / address / port from the environment (RANK, WORLD_SIZE, MASTER_ADDR,
  * MASTER_PORT; absent = a world of one).  port_offset is added to MASTER_PORT (torch.distributed's own store
  * listens on MASTER_PORT itself).  The HIP device must be current (mfem_amd_init) before the call: the RCCL

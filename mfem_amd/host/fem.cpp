@@ -881,7 +881,13 @@ void ConstrainedOperator::Mult(const Vector &x, Vector &y) const
 bool CGSolver::FusedMult(const Vector &b, Vector &x) const
 {
    mfem_amd_pa_operator op;
-   if (const ConstrainedOperator *co = dynamic_cast<const ConstrainedOperator*>(oper))
+   const mfem_amd_comm *comm = nullptr;
+   if (const ParPAOperator *po = dynamic_cast<const ParPAOperator*>(oper))
+   {
+      // CGSolver(MPI_Comm) on RAP(P, A, P): every dot product all-reduced, the exchange inside the apply
+      op = po->cop; comm = po->pfes->Comm();
+   }
+   else if (const ConstrainedOperator *co = dynamic_cast<const ConstrainedOperator*>(oper))
    {
       if (!co->pa) { return false; }
       op = co->cop;
@@ -911,8 +917,17 @@ bool CGSolver::FusedMult(const Vector &b, Vector &x) const
       rhs = &r;
    }
    Vector &sol = iterative_mode ? d : x;
-   MFEM_AMD_CALL(mfem_amd_pcg_pa(&op, jac ? jac->dinv.Read() : nullptr, rhs->Read(), sol.Write(), rel_tol, abs_tol,
-                                 max_iter, 8, ws.Write(), &res, history.data(), nullptr));
+   MFEM_VERIFY(!parallel || comm || Mpi::WorldSize() == 1, "mfem_amd: CGSolver(MPI_Comm) needs the operator of ParBilinearForm::FormLinearSystem");
+   if (comm)
+   {
+      MFEM_AMD_CALL(mfem_amd_pcg_pa_par(&op, comm, jac ? jac->dinv.Read() : nullptr, rhs->Read(), sol.Write(), rel_tol, abs_tol,
+                                        max_iter, 8, ws.Write(), &res, history.data(), nullptr));
+   }
+   else
+   {
+      MFEM_AMD_CALL(mfem_amd_pcg_pa(&op, jac ? jac->dinv.Read() : nullptr, rhs->Read(), sol.Write(), rel_tol, abs_tol,
+                                    max_iter, 8, ws.Write(), &res, history.data(), nullptr));
+   }
    if (iterative_mode) { x += d; }
    final_iter = res.iterations; converged = res.converged != 0;
    history.resize((size_t)res.iterations + 1);
@@ -920,7 +935,9 @@ bool CGSolver::FusedMult(const Vector &b, Vector &x) const
    initial_norm = nom0 >= 0.0 ? std::sqrt(nom0) : nom0;
    final_norm = betanom >= 0.0 ? std::sqrt(betanom) : betanom;
    // the reference's log, printed after the (asynchronous) solve
-   const bool it_print = print_level == 1, summary = print_level == 2, first_last = print_level == 3, warnings = print_level >= 0;
+   const bool root = !comm || Mpi::Root();       // in parallel only rank 0 prints (IterativeSolver::SetPrintLevel, solvers.cpp)
+   const bool it_print = root && print_level == 1, summary = root && print_level == 2, first_last = root && print_level == 3;
+   const bool warnings = root && print_level >= 0;
    if (it_print)
    { for (size_t i = 0; i < history.size(); i++) { mfem::out << "   Iteration : " << std::setw(3) << i << "  (B r, r) = " << history[i] << '\n'; } }
    else if (first_last)

@@ -53,6 +53,12 @@ void Device::Configure(const std::string &config, int dev)
    std::string name = config;
    size_t colon = name.find(':');
    if (colon != std::string::npos) { dev = std::atoi(name.c_str() + colon + 1); name = name.substr(0, colon); }
+   else if (dev == 0 && getenv("LOCAL_RANK"))
+   {
+      // one process per GPU: without an explicit index a rank takes the device of its LOCAL_RANK
+      int nd = 0;
+      if (hipGetDeviceCount(&nd) == hipSuccess && nd > 0) { dev = std::atoi(getenv("LOCAL_RANK")) % nd; }
+   }
    if (name == "cpu" || name == "omp" || name == "debug")
    {
       MFEM_ABORT("mfem_amd: device '" << config << "' requested, but this library computes on the "

@@ -23,6 +23,7 @@
 #include <algorithm>
 
 #include "../../include/mfem_amd.h"
+#include "../../include/mfem_amd_comm.h"
 
 namespace mfem
 {
@@ -418,13 +419,19 @@ public:
 };
 
 /// linalg/solvers.hpp:626-, solvers.cpp:855-1050.
+typedef int MPI_Comm;                      // no MPI on the target image: a tag for the process group of Mpi::World()
+constexpr MPI_Comm MPI_COMM_WORLD = 0x44000000;
+typedef long long HYPRE_BigInt;
+
 class CGSolver : public IterativeSolver
 {
    mutable Vector r, d, z, ws;
    mutable std::vector<real_t> history;
+   bool parallel = false;                  // CGSolver(MPI_Comm): dot products are all-reduced (solvers.cpp:44-54)
    bool FusedMult(const Vector &b, Vector &x) const;
 public:
    CGSolver() {}
+   explicit CGSolver(MPI_Comm) : parallel(true) {}
    void Mult(const Vector &b, Vector &x) const override;
    /// the "(B r, r)" sequence of the last solve (what print level 1 prints)
    const std::vector<real_t> &ResidualHistory() const { return history; }
@@ -716,6 +723,7 @@ class Mesh
    void Destroy();
    void Swap(Mesh &o);
    friend class FiniteElementSpace;
+   friend class ParMesh;
 public:
    Array<int> attributes, bdr_attributes;
    /// recompute `attributes` / `bdr_attributes` after SetAttribute / SetBdrAttribute (mesh/mesh.cpp SetAttributes)
@@ -726,7 +734,9 @@ public:
    Mesh(const Mesh &) = delete;
    Mesh(Mesh &&o) noexcept { Swap(o); }
    Mesh &operator=(Mesh &&o) noexcept { Swap(o); return *this; }
-   ~Mesh() { Destroy(); }
+   virtual ~Mesh() { Destroy(); }
+   /// mesh/mesh.hpp Clear(): an empty mesh
+   void Clear() { Destroy(); Mesh empty; Swap(empty); }
    /// mesh/mesh.cpp:4628-4636 (vertex/element/boundary conventions of Make3D :3684-3964)
    static Mesh MakeCartesian3D(int nx, int ny, int nz, Element::Type type, real_t sx = 1.0,
                                real_t sy = 1.0, real_t sz = 1.0, bool sfc_ordering = true);
@@ -811,7 +821,9 @@ class FiniteElementSpace
    void Construct();
 public:
    FiniteElementSpace(Mesh *mesh, const FiniteElementCollection *fec, int vdim = 1, int ordering = Ordering::byNODES);
-   ~FiniteElementSpace() { delete R_lex; }
+   virtual ~FiniteElementSpace() { delete R_lex; }
+   /// the mesh object moved (Mesh::Swap): follow it
+   void SetMesh(Mesh *m) { mesh = m; }
    FiniteElementSpace(const FiniteElementSpace &) = delete;
    Mesh *GetMesh() const { return mesh; }
    const FiniteElementCollection *FEColl() const { return fec; }
@@ -1068,6 +1080,134 @@ public:
    void Mult(const Vector &, Vector &) const override {}
 };
 }
+
+
+// ---- parallel layer: one process per GPU (mesh/pmesh.hpp, fem/pfespace.hpp, fem/pbilinearform.hpp, ...) --------
+// Vectors of a parallel space live on the rank's local dofs; entries of dofs another rank owns (ghosts) are kept at
+// zero between operator applications, so "true-dof vectors" and local vectors have one size and no T<->L copies
+// exist (the reference copies through ltdof_ldof, fem/pfespace.cpp:5385-5391).  The transport is RCCL
+// (include/mfem_amd_comm.h).
+
+/// general/communication.hpp `Mpi`: the process group comes from the launcher's environment (RANK, WORLD_SIZE,
+/// LOCAL_RANK, MASTER_ADDR, MASTER_PORT -- torch.distributed.run or any launcher that sets them).
+class Mpi
+{
+public:
+   static void Init() {}
+   static void Init(int &, char **&) {}
+   static int WorldRank();
+   static int WorldSize();
+   static bool Root() { return WorldRank() == 0; }
+   static void Finalize();
+   /// the communicator, created on first use (after the Device is configured: RCCL binds to the current GPU)
+   static mfem_amd_world *World();
+};
+class Hypre { public: static void Init() {} };
+
+/// mesh/pmesh.hpp: the rank's part of an element partition of a serial mesh.  The local part is a Mesh of its own
+/// (this object); the serial mesh and the partition stay available for the global dof numbering.
+class ParMesh : public Mesh
+{
+   MPI_Comm comm; int rank, nranks;
+   Mesh serial; std::vector<int> partition, local_elems;
+   void BuildLocal();
+public:
+   /// partitioning: rank of every element, or NULL = contiguous chunks of the element order (METIS, the
+   /// reference's default mesh/mesh.cpp:9106-9195, is not on the target image).  `mesh` is emptied (moved from).
+   ParMesh(MPI_Comm comm, Mesh &mesh, const int *partitioning = nullptr);
+   MPI_Comm GetComm() const { return comm; }
+   int GetMyRank() const { return rank; }
+   int GetNRanks() const { return nranks; }
+   long long GetGlobalNE() const { return serial.GetNE(); }
+   /// mesh/pmesh.cpp UniformRefinement: children inherit their parent's rank
+   void UniformRefinement(int ref_algo = 0);
+   const Mesh &SerialMesh() const { return serial; }
+   const std::vector<int> &LocalElements() const { return local_elems; }
+   const std::vector<int> &Partitioning() const { return partition; }
+};
+
+/// fem/pfespace.hpp: local H1 space + the shared-dof tables of DeviceConformingProlongationOperator
+/// (fem/pfespace.cpp:5266-5345) + the exchange.
+class ParFiniteElementSpace : public FiniteElementSpace
+{
+   ParMesh *pmesh;
+   FiniteElementSpace *gfes = nullptr;          // the serial space: global dof numbering (every rank has it)
+   Array<int> l2g;                              // local dof -> global dof
+   Array<int> shr_ltdof, ext_ldof, unq_ltdof, unq_shr_i, unq_shr_j;
+   std::vector<int> up_ranks, up_sizes, lo_ranks, lo_sizes;
+   mfem_amd_exchange *exchange = nullptr;
+   mfem_amd_comm cb;
+   int n_owned = 0;
+   void BuildSharedTables();
+public:
+   ParFiniteElementSpace(ParMesh *pm, const FiniteElementCollection *fec, int vdim = 1, int ordering = Ordering::byNODES);
+   ~ParFiniteElementSpace();
+   ParMesh *GetParMesh() const { return pmesh; }
+   MPI_Comm GetComm() const { return pmesh->GetComm(); }
+   HYPRE_BigInt GlobalTrueVSize() const { return gfes->GetNDofs(); }
+   HYPRE_BigInt GlobalVSize() const { return gfes->GetNDofs(); }
+   int GetTrueVSize() const { return GetVSize(); }
+   int GetNOwned() const { return n_owned; }
+   const Array<int> &LocalToGlobal() const { return l2g; }
+   const Array<int> &GhostDofs() const { return ext_ldof; }
+   /// fem/pfespace.cpp GetEssentialTrueDofs: the marker is synchronised over the sharing ranks there; here it is
+   /// taken from the serial space, which every rank holds.  Ghost copies of essential dofs are in the list too.
+   void GetEssentialTrueDofs(const Array<int> &bdr_attr_is_ess, Array<int> &ess_tdof_list, int component = -1) const;
+   const mfem_amd_comm *Comm() const { return &cb; }
+   void Forward(Vector &v) const;               // P: ghosts := owner values
+   void Reverse(Vector &v) const;               // P^T: owners += ghost contributions; ghosts := 0
+};
+
+class ParGridFunction : public GridFunction
+{
+   ParFiniteElementSpace *pfes;
+public:
+   explicit ParGridFunction(ParFiniteElementSpace *f) : GridFunction(f), pfes(f) {}
+   ParGridFunction &operator=(real_t v) { Vector::operator=(v); return *this; }
+   ParGridFunction &operator=(const Vector &v) { Vector::operator=(v); return *this; }
+   ParFiniteElementSpace *ParFESpace() const { return pfes; }
+};
+
+class ParLinearForm : public LinearForm
+{
+   ParFiniteElementSpace *pfes;
+public:
+   explicit ParLinearForm(ParFiniteElementSpace *f) : LinearForm(f), pfes(f) {}
+   ParFiniteElementSpace *ParFESpace() const { return pfes; }
+   /// fem/plinearform.cpp ParallelAssemble: tv = P^T b
+   void ParallelAssemble(Vector &tv) const { tv = *this; pfes->Reverse(tv); }
+};
+
+/// RAPOperator(P, ConstrainedOperator(A), P) of the PA form (linalg/operator.cpp:433, 586-646) on the local vectors
+class ParPAOperator : public Operator
+{
+   const ParFiniteElementSpace *pfes;
+   mutable mfem_amd_pa_operator cop;
+   Array<int> ess; Array<unsigned char> marker; Array<int> masked_gather;
+   friend class CGSolver;
+public:
+   ParPAOperator(const PABilinearFormExtension &ext, const ParFiniteElementSpace &pfes, const Array<int> &ess_tdof_list);
+   /// the ghost entries of x are overwritten with their owners' values (P is applied in place)
+   void Mult(const Vector &x, Vector &y) const override;
+   const Array<int> &GetEssentialTrueDofs() const { return ess; }
+};
+
+/// fem/pbilinearform.hpp, PARTIAL assembly level only
+class ParBilinearForm : public BilinearForm
+{
+   ParFiniteElementSpace *pfes;
+public:
+   explicit ParBilinearForm(ParFiniteElementSpace *f) : BilinearForm(f), pfes(f) {}
+   ParFiniteElementSpace *ParFESpace() const { return pfes; }
+   /// y = P^T A P x
+   void Mult(const Vector &x, Vector &y) const override;
+   /// fem/pbilinearform.cpp:293-316: local diagonal, one P^T exchange; ghost entries read +infinity (1/diag = 0)
+   void AssembleDiagonal(Vector &diag) const override;
+   void FormLinearSystem(const Array<int> &ess_tdof_list, Vector &x, Vector &b, OperatorHandle &A,
+                         Vector &X, Vector &B, int copy_interior = 0);
+   /// x = P X
+   void RecoverFEMSolution(const Vector &X, const Vector &b, Vector &x) override;
+};
 
 } // namespace mfem
 #endif

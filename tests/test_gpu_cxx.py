@@ -195,3 +195,55 @@ def test_cxx_mult_transpose_of_nonsymmetric_form_aborts(tmp_path):
     out = subprocess.run([str(BIN / "dump_tables"), str(tmp_path)] + spec, capture_output=True, text=True, timeout=300, cwd=str(ROOT))
     assert out.returncode != 0
     assert "only implemented in the symmetric case" in out.stderr + out.stdout
+
+
+# ---- the parallel C++ layer: ex1p on ParMesh / ParFiniteElementSpace / ParBilinearForm / CGSolver(MPI_COMM_WORLD) ----
+def _run_ex1p(nranks, args, transport):
+    """one process per rank, launched the way any launcher would: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* in the
+    environment.  Several ranks on the one GPU of the test box use the host-staged TCP transport."""
+    import os
+    port = 31500 + os.getpid() % 1500 + 7*nranks
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), MFEM_AMD_TRANSPORT=transport)
+        procs.append(subprocess.Popen([str(BIN / "ex1p")] + [str(a) for a in args], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True, env=env, cwd=str(ROOT)))
+    outs = [p.communicate(timeout=280) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so[-1500:] + se[-2500:]
+    return outs[0][0]
+
+
+@pytest.mark.parametrize("mesh,order", [("inline-hex.mesh", 3), ("toroid-hex.mesh", 2)])
+def test_ex1p_cxx_ranks_match_serial_ex1(mesh, order):
+    """examples/ex1p.cpp with 1 rank on RCCL and 2, 3 ranks over the TCP transport (one GPU) against the serial
+    ex1 on the same refined mesh: unknown count, (B r, r) history, solution norm."""
+    m = MESHES / mesh
+    ser = run([BIN / "ex1", "-m", m, "-o", order, "-r", 2, "-pa", "-d", "hip", "-no-vis", "-no-save"])
+    n_ser, h_ser = parse_ex1(ser)
+    nrm_ser = float(re.search(r"\|x\|_2 = (\S+)", ser).group(1))
+    res = {}
+    for nr, tr in ((1, "rccl"), (2, "tcp"), (3, "tcp")):
+        txt = _run_ex1p(nr, ["-m", m, "-o", order, "-r", 1, "-rp", 1, "-pa", "-d", "hip", "-no-vis", "-no-save"], tr)
+        assert f"ranks = {nr}" in txt
+        n, h = parse_ex1(txt)
+        nrm = float(re.search(r"\|x\|_2 = (\S+)", txt).group(1))
+        res[nr] = (n, np.array(h), nrm)
+        assert n == n_ser
+        # converged to rel tol 1e-12: same solution as the serial solve (which stops at 1e-6) to its accuracy
+        assert abs(nrm - nrm_ser) <= 1e-5*nrm_ser, (nr, nrm, nrm_ser)
+    h1 = res[1][1]
+    for nr in (2, 3):
+        h = res[nr][1]
+        assert abs(len(h) - len(h1)) <= 1
+        k = min(len(h), len(h1))
+        big = h1[:k] > 1e-10*h1[0]
+        assert np.all(np.abs(h[:k][big] - h1[:k][big]) <= 1e-5*h1[:k][big]), nr      # 6 printed digits
+        assert abs(res[nr][2] - res[1][2]) <= 1e-10*res[1][2]
+    # against the serial example where both are above rounding (different dof numbering and dot order)
+    k = min(len(h1), len(h_ser))
+    hs = np.array(h_ser[:k])
+    big = hs > 1e-10*hs[0]
+    assert np.all(np.abs(h1[:k][big] - hs[big]) <= 1e-3*hs[big])
+    assert np.all(np.abs(h1[:6] - hs[:6]) <= 2e-6*hs[:6])
