@@ -320,6 +320,8 @@ typedef struct mfem_amd_pcg_result
    int converged;       /* CGSolver::GetConverged */
    double initial_nom;  /* (B r, r) at iteration 0 */
    double final_nom;    /* (B r, r) at the last iteration; final_norm = sqrt */
+   int history_count;   /* entries written to hist: iterations + 1, or iterations when the solve ended on a
+                           zero / non-finite (A d, d) after the iteration count was advanced (solvers.cpp:1011-1025) */
 } mfem_amd_pcg_result;
 
 /* Bytes of device workspace mfem_amd_pcg_pa needs for n unknowns (3 vectors, reduction

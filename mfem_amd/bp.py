@@ -248,4 +248,4 @@ class BakeoffProblem:
                                               max_iter, check_every, _p(self._ws), C.byref(res), hp, self.stream)
             if rc != 0:
                 raise capi.MfemAmdError(f"{capi.lib.mfem_amd_last_error().decode()} / {self.ex.error!r}")
-        return x, res, (hist[:res.iterations + 1] if want_hist else None)
+        return x, res, (hist[:res.history_count] if want_hist else None)

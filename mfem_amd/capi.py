@@ -47,7 +47,7 @@ class Comm(C.Structure):
 
 class PcgResult(C.Structure):
     """struct mfem_amd_pcg_result"""
-    _fields_ = [("iterations", cint), ("converged", cint), ("initial_nom", dbl), ("final_nom", dbl)]
+    _fields_ = [("iterations", cint), ("converged", cint), ("initial_nom", dbl), ("final_nom", dbl), ("history_count", cint)]
 
 
 _SIGS = {

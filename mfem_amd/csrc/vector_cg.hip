@@ -126,6 +126,7 @@ struct PcgState
    int converged;
    int max_iter;
    double rel_tol, abs_tol;
+   int hist_n;      // entries of the (B r, r) history written so far
 };
 
 // r = b; x = 0; z = dinv.r (or r); d = z; partial d.r
@@ -159,6 +160,7 @@ k_pcg_init_scalars(const int nb, const double *__restrict__ partials, PcgState *
    {
       st->nom = st->nom0 = st->betanom = nom;
       st->iter = 0; st->converged = 0; st->done = 0;
+      st->hist_n = 1;
       if (hist) { hist[0] = nom; }
       const double r0 = fmax(nom*st->rel_tol*st->rel_tol, st->abs_tol*st->abs_tol);
       st->r0 = r0;
@@ -223,6 +225,7 @@ k_pcg_beta_scalars(const int nb, const double *__restrict__ partials, PcgState *
    {
       const int i = st->iter + 1;        // the iteration whose update just ran
       st->betanom = betanom;
+      st->hist_n = i + 1;
       if (hist) { hist[i] = betanom; }
       if (!(betanom >= 0.0)) { st->iter = i; st->done = 1; }
       else if (betanom <= st->r0) { st->iter = i; st->converged = 1; st->done = 1; }
@@ -542,9 +545,11 @@ static int pcg_impl(const mfem_amd_pa_operator *op, const mfem_amd_comm *comm, c
    result->converged = cur.converged;
    result->initial_nom = cur.nom0;
    result->final_nom = cur.betanom;
+   // a breakdown (zero or NaN curvature) ends the solve one count past the last residual the reference prints
+   result->history_count = cur.hist_n < result->iterations + 1 ? cur.hist_n : result->iterations + 1;
    if (hist)
    {
-      const int cnt = result->iterations + 1;
+      const int cnt = result->history_count;
       if (int rc = check_hip(hipMemcpyAsync(hist, dhist, sizeof(double)*cnt, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(hist)")) { return rc; }
       if (int rc = check_hip(hipStreamSynchronize(s), "hipStreamSynchronize")) { return rc; }
    }

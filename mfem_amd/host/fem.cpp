@@ -861,11 +861,22 @@ void ConstrainedOperator::EliminateRHS(const Vector &x, Vector &b) const
    b -= z;
    if (n) { MFEM_AMD_CALL(mfem_amd_set_subvector(n, constraint_list.Read(), x.Read(), 0.0, b.ReadWrite(), nullptr)); }
 }
+// The form may have been re-assembled since the constructor ran (its device buffers move when they grow): take
+// the extension's current pointers before every use, as the reference's A->Mult always sees the current state.
+void ConstrainedOperator::RefreshOperator() const
+{
+   if (!pa) { return; }
+   const int64_t ness = cop.ness;
+   MFEM_VERIFY(pa->FillOperator(cop), "mfem_amd: the form behind the ConstrainedOperator lost its partial assembly");
+   cop.ness = ness; cop.ess = ness ? constraint_list.Read() : nullptr; cop.ess_marker = marker.Read();
+   if (ness && cop.vdim == 0) { cop.masked_gather_map = masked_gather.Read(); }
+}
 void ConstrainedOperator::Mult(const Vector &x, Vector &y) const
 {
    MFEM_VERIFY(x.Size() == Width() && y.Size() == Height(), "incompatible sizes");
    if (pa)
    {
+      RefreshOperator();
       MFEM_AMD_CALL(mfem_amd_pa_constrained_mult(&cop, x.Read(), y.Write(), nullptr));
       return;
    }
@@ -885,11 +896,13 @@ bool CGSolver::FusedMult(const Vector &b, Vector &x) const
    if (const ParPAOperator *po = dynamic_cast<const ParPAOperator*>(oper))
    {
       // CGSolver(MPI_Comm) on RAP(P, A, P): every dot product all-reduced, the exchange inside the apply
+      po->RefreshOperator();
       op = po->cop; comm = po->pfes->Comm();
    }
    else if (const ConstrainedOperator *co = dynamic_cast<const ConstrainedOperator*>(oper))
    {
       if (!co->pa) { return false; }
+      co->RefreshOperator();
       op = co->cop;
    }
    else
@@ -930,7 +943,7 @@ bool CGSolver::FusedMult(const Vector &b, Vector &x) const
    }
    if (iterative_mode) { x += d; }
    final_iter = res.iterations; converged = res.converged != 0;
-   history.resize((size_t)res.iterations + 1);
+   history.resize((size_t)res.history_count);
    const real_t nom0 = res.initial_nom, betanom = res.final_nom;
    initial_norm = nom0 >= 0.0 ? std::sqrt(nom0) : nom0;
    final_norm = betanom >= 0.0 ? std::sqrt(betanom) : betanom;

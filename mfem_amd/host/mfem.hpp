@@ -365,6 +365,7 @@ protected:
    const PABilinearFormExtension *pa = nullptr;     // fast path: fused masked apply
    mutable mfem_amd_pa_operator cop;
    Array<unsigned char> marker; Array<int> masked_gather;
+   void RefreshOperator() const;
    friend class CGSolver;
 public:
    ConstrainedOperator(Operator *A, const Array<int> &list, bool own_A = false,
@@ -1182,8 +1183,10 @@ public:
 class ParPAOperator : public Operator
 {
    const ParFiniteElementSpace *pfes;
+   const PABilinearFormExtension *pa;
    mutable mfem_amd_pa_operator cop;
    Array<int> ess; Array<unsigned char> marker; Array<int> masked_gather;
+   void RefreshOperator() const;
    friend class CGSolver;
 public:
    ParPAOperator(const PABilinearFormExtension &ext, const ParFiniteElementSpace &pfes, const Array<int> &ess_tdof_list);

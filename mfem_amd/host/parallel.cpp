@@ -244,7 +244,7 @@ void ParFiniteElementSpace::Reverse(Vector &v) const
 
 // ---- ParPAOperator --------------------------------------------------------------------------------
 ParPAOperator::ParPAOperator(const PABilinearFormExtension &ext, const ParFiniteElementSpace &pf, const Array<int> &ess_list)
-   : Operator(pf.GetVSize()), pfes(&pf)
+   : Operator(pf.GetVSize()), pfes(&pf), pa(&ext)
 {
    MFEM_VERIFY(ext.FillOperator(cop), "mfem_amd: the parallel operator needs a form with one assembled domain integrator");
    ess_list.Copy(ess);
@@ -263,9 +263,18 @@ ParPAOperator::ParPAOperator(const PABilinearFormExtension &ext, const ParFinite
    }
    cop.ness = ness; cop.ess = ness ? ess.Read() : nullptr; cop.ess_marker = marker.Read();
 }
+// as ConstrainedOperator::RefreshOperator (fem.cpp): the form's buffers may have moved since construction
+void ParPAOperator::RefreshOperator() const
+{
+   const int64_t ness = cop.ness;
+   MFEM_VERIFY(pa->FillOperator(cop), "mfem_amd: the form behind the parallel operator lost its partial assembly");
+   cop.ness = ness; cop.ess = ness ? ess.Read() : nullptr; cop.ess_marker = marker.Read();
+   if (ness) { cop.masked_gather_map = masked_gather.Read(); }
+}
 void ParPAOperator::Mult(const Vector &x, Vector &y) const
 {
    MFEM_VERIFY(x.Size() == Width() && y.Size() == Height(), "incompatible sizes");
+   RefreshOperator();
    MFEM_AMD_CALL(mfem_amd_pa_par_mult(&cop, pfes->Comm(), const_cast<Vector&>(x).ReadWrite(), y.Write(), nullptr));
 }
 

@@ -84,4 +84,4 @@ class DeviceOperator:
         hist = np.zeros(max_iter + 2)
         capi.call("mfem_amd_pcg_pa", C.byref(self.op), ptr(dinv), ptr(b), ptr(x), rel_tol, abs_tol, max_iter,
                   check_every, ptr(ws), C.byref(res), hist.ctypes.data_as(C.c_void_p), None)
-        return x, res, hist[:res.iterations + 1]
+        return x, res, hist[:res.history_count]

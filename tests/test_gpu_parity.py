@@ -177,6 +177,32 @@ def test_constrained_operator_and_pcg(gh, name):
     assert np.array_equal(gh.host(X1), gh.host(X2)) and np.array_equal(h1, h2)
 
 
+def test_pcg_curvature_breakdown_counts(gh):
+    """(A d, d) = 0: CGSolver::Mult leaves with converged = false (linalg/solvers.cpp:930-940 at iteration 0,
+    :1011-1025 inside the loop, where the count has been advanced past the last residual it printed).
+    Operator: zero coefficient, so the constrained operator is the identity on the essential dofs and 0 elsewhere."""
+    c = dict(load_case(CASES[0]))
+    c["pa_data"] = np.zeros_like(c["pa_data"])
+    n = c["ndofs"]
+    ess = np.arange(0, 4, dtype=np.int32)
+    # (1) no essential dofs: A = 0, (A d, d) = 0 at the start -> 0 iterations, one history entry
+    op0 = gh.DeviceOperator(c, None)
+    b = np.ones(n)
+    X, res, hist = op0.pcg(gh.dev(b), None, 1e-12, max_iter=10)
+    assert (res.iterations, res.converged, res.history_count) == (0, 0, 1) and hist[0] == float(n)
+    assert not gh.host(X).any()
+    # (2) b = 1 on 4 essential and 4 other dofs: alpha = 2, r = (-1, 1), beta = 1, d = (0, 2): every step exact,
+    #     (A d, d) = 0 at the second direction -> final_iter = 2 with the residuals of iterations 0 and 1 only
+    op = gh.DeviceOperator(c, ess)
+    b = np.zeros(n); b[:8] = 1.0
+    for check_every in (1, 3):
+        X, res, hist = op.pcg(gh.dev(b), None, 1e-12, max_iter=10, check_every=check_every)
+        assert (res.iterations, res.converged, res.history_count) == (2, 0, 2), (res.iterations, res.converged, res.history_count)
+        assert list(hist) == [8.0, 8.0] and res.final_nom == 8.0
+        x = gh.host(X)
+        assert np.array_equal(x[:8], 2.0*np.ones(8)) and not x[8:].any()
+
+
 def test_vector_kernels(gh):
     from mfem_amd import capi
     for n in (1, 255, 4099, 1_000_003):
