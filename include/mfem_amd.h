@@ -331,8 +331,8 @@ int64_t mfem_amd_pcg_workspace_bytes(int64_t n, int max_iter);
  * by OperatorJacobiSmoother (dinv != NULL) or not (dinv == NULL, bench_ceed.cpp:117-121).
  * Stopping rule (:919,988): stop when (B r, r) <= max((B r, r)_0*rel_tol^2, abs_tol^2);
  * max_iter as the reference.  Vector updates are fused (kernel A
- * {x += alpha d; r -= alpha z; z = dinv r; partial r.z}, kernel B {d = z + beta d}, d.Ad in
- * the transpose-gather epilogue); alpha, beta, the residual norms and the stop flag live
+ * {r -= alpha z; z = dinv r; partial r.z}, kernel B {x += alpha d; d = z + beta d}, d.Ad in
+ * the transpose-gather epilogue: 11 vector passes per iteration); alpha, beta, the residual norms and the stop flag live
  * on the device, so no host synchronisation happens inside the loop: the host polls the
  * flag every `check_every` iterations (>= 1) and kernels launched after convergence are
  * no-ops, so the iteration count is exactly the reference's.

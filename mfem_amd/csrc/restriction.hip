@@ -167,6 +167,10 @@ __device__ __forceinline__ void scatter_block_rows(const int64_t ndofs, const in
       const int64_t last = ndofs - 1;
       int o0[4], n[4];
       double val[4];
+      // the epilogue's operands (essential marker, d of the d.Ad sum) are requested now, so that they arrive
+      // while the entries are gathered instead of after the row sums
+      unsigned char mk[4];
+      double wv[4];
 #pragma unroll
       for (int j = 0; j < 4; j++)
       {
@@ -174,6 +178,8 @@ __device__ __forceinline__ void scatter_block_rows(const int64_t ndofs, const in
          const int64_t ic = i < ndofs ? i : last;
          o0[j] = offsets[ic];
          n[j] = i < ndofs ? offsets[ic + 1] - o0[j] : 0;
+         mk[j] = marker ? marker[ic] : (unsigned char)0;
+         wv[j] = DOT ? w[ic] : 0.0;
       }
       const int64_t rend = base + 1024 < ndofs ? base + 1024 : ndofs;
       const int o_lo = offsets[base], nent = offsets[rend] - o_lo;
@@ -227,14 +233,10 @@ __device__ __forceinline__ void scatter_block_rows(const int64_t ndofs, const in
          if (i < ndofs)
          {
             double r = val[j];
-            if (marker)
-            {
-               const unsigned char m = marker[i];
-               if (m) { r = (m == 1) ? xin[i] : 0.0; }
-            }
+            if (mk[j]) { r = (mk[j] == 1) ? xin[i] : 0.0; }
             if (MODE == 1) { r += y[i]; }
             y[i] = r;
-            if (DOT) { prod += w[i]*r; }
+            if (DOT) { prod += wv[j]*r; }
          }
       }
    }

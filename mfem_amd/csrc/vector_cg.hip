@@ -6,10 +6,10 @@
 //
 // The reference runs one kernel per BLAS-1 call (22 vector passes per PCG iteration) and
 // synchronises the host twice per iteration to read the dot products.  Here one iteration
-// is: kernel A {x += alpha d; r -= alpha z; z = dinv.r; partial r.z}, a one-workgroup
-// scalar kernel, kernel B {d = z + beta d}, the fused gather+apply kernel, the
+// is: kernel A {r -= alpha z; z = dinv.r; partial r.z}, a one-workgroup scalar kernel,
+// kernel B {x += alpha d; d = z + beta d}, the fused gather+apply kernel, the
 // transpose-gather kernel with the d.Ad partial folded into its epilogue, and a second
-// scalar kernel -- 12 vector passes; alpha/beta/(Br,r) and the stop flag stay on the device.
+// scalar kernel -- 11 vector passes; alpha/beta/(Br,r) and the stop flag stay on the device.
 // All reductions have a fixed shape that depends on n only (wavefront shuffles, fixed-order
 // LDS combine, fixed-order final pass), so repeated runs are bit-identical.
 #include "common.h"
@@ -127,7 +127,22 @@ struct PcgState
    int max_iter;
    double rel_tol, abs_tol;
    int hist_n;      // entries of the (B r, r) history written so far
+   int k;           // k_pcg_beta_scalars launches so far (no-op launches after the end included)
 };
+
+// den = (d, A d) after the first/each operator application (linalg/solvers.cpp:931-949, 1010-1025);
+// nom <- betanom at the end of an iteration.  One thread.
+__device__ __forceinline__ void pcg_den_step(PcgState *st, const double den, const int first)
+{
+   st->den = den;
+   if (!first) { st->nom = st->betanom; }
+   if (den == 0.0 || den != den)                           // (linalg/solvers.cpp:940-948, 1019-1023)
+   {
+      st->done = 1;
+      if (!first) { st->iter += 1; }                       // the reference has already done ++i
+   }
+   else { st->alpha = st->nom/den; }
+}
 
 // r = b; x = 0; z = dinv.r (or r); d = z; partial d.r
 __global__ void __launch_bounds__(256)
@@ -160,7 +175,7 @@ k_pcg_init_scalars(const int nb, const double *__restrict__ partials, PcgState *
    {
       st->nom = st->nom0 = st->betanom = nom;
       st->iter = 0; st->converged = 0; st->done = 0;
-      st->hist_n = 1;
+      st->hist_n = 1; st->k = 0;
       if (hist) { hist[0] = nom; }
       const double r0 = fmax(nom*st->rel_tol*st->rel_tol, st->abs_tol*st->abs_tol);
       st->r0 = r0;
@@ -178,24 +193,27 @@ k_pcg_den_scalars(const int nb, const double *__restrict__ partials, PcgState *s
    __shared__ double s4[4];
    if (st->done) { return; }
    const double den = gsum ? *gsum : final_sum(partials, nb, s4);
-   if (threadIdx.x == 0)
-   {
-      st->den = den;
-      if (!first) { st->nom = st->betanom; }
-      if (den == 0.0 || den != den)                           // (linalg/solvers.cpp:940-948, 1019-1023)
-      {
-         st->done = 1;
-         if (!first) { st->iter += 1; }                       // the reference has already done ++i
-      }
-      else { st->alpha = st->nom/den; }
-   }
+   if (threadIdx.x == 0) { pcg_den_step(st, den, first); }
 }
 
-// kernel A: x += alpha d; r -= alpha z; z = dinv.r (or r); partial (r, z)
+// betanom, convergence test, iteration count, beta (linalg/solvers.cpp:963-1000).  One thread.
+__device__ __forceinline__ void pcg_beta_step(PcgState *st, const double betanom, double *__restrict__ hist)
+{
+   const int i = st->iter + 1;        // the iteration whose update just ran
+   st->betanom = betanom;
+   st->hist_n = i + 1;
+   if (hist) { hist[i] = betanom; }
+   if (!(betanom >= 0.0)) { st->iter = i; st->done = 1; }
+   else if (betanom <= st->r0) { st->iter = i; st->converged = 1; st->done = 1; }
+   else if (i + 1 > st->max_iter) { st->iter = st->max_iter; st->done = 1; }
+   else { st->iter = i; st->beta = betanom/st->nom; }
+}
+
+// kernel A: r -= alpha z; z = dinv.r (or r); partial (r, z).  (x += alpha d rides with kernel B, which reads d
+// anyway: one pass over d less per iteration, the same x bit for bit.)
 __global__ void __launch_bounds__(256)
 k_pcg_update(const int64_t n, const PcgState *__restrict__ st, const double *__restrict__ dinv,
-             const double *__restrict__ d, double *__restrict__ x, double *__restrict__ r,
-             double *__restrict__ z, double *__restrict__ partials)
+             double *__restrict__ r, double *__restrict__ z, double *__restrict__ partials)
 {
    __shared__ double s4[4];
    if (st->done) { return; }
@@ -203,7 +221,6 @@ k_pcg_update(const int64_t n, const PcgState *__restrict__ st, const double *__r
    double acc = 0.0;
    for (int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x; i < n; i += (int64_t)gridDim.x*256)
    {
-      x[i] = x[i] + alpha*d[i];
       const double ri = r[i] + (-alpha)*z[i];
       const double zi = dinv ? dinv[i]*ri : ri;
       r[i] = ri; z[i] = zi;
@@ -213,37 +230,40 @@ k_pcg_update(const int64_t n, const PcgState *__restrict__ st, const double *__r
    if (threadIdx.x == 0) { partials[blockIdx.x] = s; }
 }
 
-// betanom, convergence test, iteration count, beta (linalg/solvers.cpp:963-1000).
 __global__ void __launch_bounds__(256)
 k_pcg_beta_scalars(const int nb, const double *__restrict__ partials, PcgState *st,
                    double *__restrict__ hist, const double *__restrict__ gsum)
 {
    __shared__ double s4[4];
+   if (threadIdx.x == 0) { st->k = st->k + 1; }        // counts every launch: kernel B tells its iteration by it
    if (st->done) { return; }
    const double betanom = gsum ? *gsum : final_sum(partials, nb, s4);
-   if (threadIdx.x == 0)
-   {
-      const int i = st->iter + 1;        // the iteration whose update just ran
-      st->betanom = betanom;
-      st->hist_n = i + 1;
-      if (hist) { hist[i] = betanom; }
-      if (!(betanom >= 0.0)) { st->iter = i; st->done = 1; }
-      else if (betanom <= st->r0) { st->iter = i; st->converged = 1; st->done = 1; }
-      else if (i + 1 > st->max_iter) { st->iter = st->max_iter; st->done = 1; }
-      else { st->iter = i; st->beta = betanom/st->nom; }
-   }
+   if (threadIdx.x == 0) { pcg_beta_step(st, betanom, hist); }
 }
 
-// kernel B: d = z + beta d
+// kernel B: x += alpha d (the update of the iteration whose kernel A just ran: the reference updates x before it
+// tests convergence, linalg/solvers.cpp:957-958, so the last iteration's update is applied as well); then, unless
+// the solve has ended, d = z + beta d.  Launches after the end change nothing.
 __global__ void __launch_bounds__(256)
 k_pcg_dir(const int64_t n, const PcgState *__restrict__ st, const double *__restrict__ z,
-          double *__restrict__ d)
+          double *__restrict__ d, double *__restrict__ x)
 {
-   if (st->done) { return; }
-   const double beta = st->beta;
+   const bool xup = st->k == st->hist_n - 1;      // kernel A of this iteration ran (its (B r, r) is the last recorded)
+   if (!xup) { return; }
+   const double alpha = st->alpha, beta = st->beta;
+   if (st->done)
+   {
+      for (int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x; i < n; i += (int64_t)gridDim.x*256)
+      {
+         x[i] = x[i] + alpha*d[i];
+      }
+      return;
+   }
    for (int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x; i < n; i += (int64_t)gridDim.x*256)
    {
-      d[i] = z[i] + beta*d[i];
+      const double di = d[i];
+      x[i] = x[i] + alpha*di;
+      d[i] = z[i] + beta*di;
    }
 }
 
@@ -515,6 +535,8 @@ static int pcg_impl(const mfem_amd_pa_operator *op, const mfem_amd_comm *comm, c
    MFA_CHECK_LAUNCH("k_pcg_den_scalars");
 
    // The reference's loop body runs at least once, even for max_iter == 0.
+   // (Finishing the two reductions inside the kernels that produce them, by the last workgroup to arrive, was
+   // measured and rejected: profiles/r2/pcg_fused_finish_probe.txt.)
    const int total = max_iter > 0 ? max_iter : 1;
    PcgState cur;
    int launched = 0;
@@ -527,10 +549,10 @@ static int pcg_impl(const mfem_amd_pa_operator *op, const mfem_amd_comm *comm, c
       if (batch > total - launched) { batch = total - launched; }
       for (int k = 0; k < batch; k++)
       {
-         k_pcg_update<<<dim3(nb), dim3(256), 0, s>>>(n, st, dinv, d, x, r, z, partials);
+         k_pcg_update<<<dim3(nb), dim3(256), 0, s>>>(n, st, dinv, r, z, partials);
          if (int rc = global_sum()) { return rc; }
          k_pcg_beta_scalars<<<dim3(1), dim3(256), 0, s>>>(nb, partials, st, dhist, gs);
-         k_pcg_dir<<<dim3(sg), dim3(256), 0, s>>>(n, st, z, d);
+         k_pcg_dir<<<dim3(sg), dim3(256), 0, s>>>(n, st, z, d, x);
          MFA_CHECK_LAUNCH("pcg iteration kernels");
          if (int rc = constrained_mult(op, comm, d, z, d, partials, nb, &st->done, s)) { return rc; }
          if (int rc = global_sum()) { return rc; }
