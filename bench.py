@@ -120,6 +120,7 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1)*1e-3
 
+    quiesce()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -142,6 +143,7 @@ def main():
 
     # per-kernel average launch durations on this rank (HIP events on the launch stream), K launches per
     # block; the median of three blocks (box-to-box and clock noise is +-5 % on a 17 ms block)
+    quiesce()
     med3 = lambda fn: sorted(timed(fn, args.steps) for _ in range(3))[1]/args.steps
     t_l2e = med3(lambda: bp.l2e(x))
     t_e2l = med3(lambda: bp.e2l(y))
@@ -164,7 +166,7 @@ def main():
         if world > 1 and bp.ghost.numel():
             rhs[bp.ghost.long()] = 0.0
         bp.pcg(rhs, 0.0, max_iter=3, check_every=3)
-        torch.cuda.synchronize()
+        quiesce()
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
@@ -216,6 +218,17 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def quiesce():
+    """Before a timed region: run the cyclic garbage collector NOW and drain the device.  A collection that starts
+    inside a timed loop frees the previous workload's tensors there, and releasing device memory stalls the queue for
+    ~30 ms -- one such event inside a 20-launch loop reads as a 10x slower kernel (profiles/r2/stall_gc0.txt vs
+    stall_gc1.txt, profiles/r2/slow_launch_trace_report.txt: every kernel of the slow loop has its normal duration)."""
+    import gc
+    import torch
+    gc.collect()
+    torch.cuda.synchronize()
 
 
 def make_exchange(part, dev, vdim, rank, world):
@@ -281,7 +294,7 @@ def size_row(problem, p, dofs, dev, gen, cg_iters=20):
 
     for _ in range(3):
         bq.mult(xq, yq)
-    torch.cuda.synchronize()
+    quiesce()
     if graph:
         side = torch.cuda.Stream(dev)
         gr = torch.cuda.CUDAGraph()
@@ -304,7 +317,7 @@ def size_row(problem, p, dofs, dev, gen, cg_iters=20):
         rhs = torch.rand(bq.ndofs, dtype=torch.float64, generator=gen).to(dev)
         rhs[bq.ess.long()] = 0.0
         bq.pcg(rhs, 0.0, max_iter=3, check_every=3)
-        torch.cuda.synchronize()
+        quiesce()
         t0 = time.perf_counter()
         _, res, _ = bq.pcg(rhs, 0.0, max_iter=cg_iters, check_every=cg_iters)
         torch.cuda.synchronize()
