@@ -46,7 +46,10 @@ const char *mfem_amd_last_error(void);
  * MFEM_REPORT_KERNELS (fem/kernel_reporter.hpp:54-98). Also enabled by that env var. */
 void mfem_amd_report_kernels(int on);
 /* 1 if (D1D,Q1D) has a compile-time specialised apply kernel, else 0 (the dispatch-table
- * query, fem/kernel_dispatch.hpp:166-181).  kind: 0 = mass, 1 = diffusion. */
+ * query, fem/kernel_dispatch.hpp:166-181).  kind: 0 = mass, 1 = diffusion.  Registered: D1D = 2..9 with
+ * Q1D = D1D or D1D + 1, plus the reference's over-integrated "others" (bilininteg_diffusion_kernels.cpp:62-63,
+ * bilininteg_mass_kernels.cpp:59,66-68): (4,6), (5,8) for both, (2,4), (3,6) for mass.  MFEM_AMD_TRACE=1 in
+ * the environment wraps the stages of the path in roctx ranges (rocprofv3 --marker-trace). */
 int mfem_amd_has_specialization(int kind, int D1D, int Q1D);
 
 /* ---- ElementRestriction (fem/restriction.cpp) ------------------------------------ */

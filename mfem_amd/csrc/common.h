@@ -85,6 +85,20 @@ __host__ __device__ inline int64_t blocked_size(int kind, int Q, int64_t ne)
    return ((ne + NBZ - 1)/NBZ)*NBZ*(int64_t)(kind ? 6 : 1)*Q*Q*Q;
 }
 
+// Named ranges around the stages of the path, the role of MFEM_PERF_SCOPE (general/annotation.hpp:21-31, Caliper
+// there): with MFEM_AMD_TRACE=1 in the environment they are roctx ranges (`rocprofv3 --marker-trace --kernel-trace`
+// shows which kernels belong to which stage); otherwise they cost one load and a branch.  The roctx library is
+// looked up at run time (librocprofiler-sdk-roctx, else libroctx64): nothing is linked.
+void trace_push(const char *name);
+void trace_pop();
+struct TraceRange
+{
+   explicit TraceRange(const char *name) { trace_push(name); }
+   ~TraceRange() { trace_pop(); }
+   TraceRange(const TraceRange&) = delete;
+   TraceRange &operator=(const TraceRange&) = delete;
+};
+
 void set_error(const char *fmt, ...);
 int check_hip(hipError_t e, const char *what);
 bool report_kernels_enabled();

@@ -33,9 +33,14 @@ namespace mfa
 
 // Register budget hint (waves per SIMD the kernel should fit, 2nd __launch_bounds__ argument
 // on AMD): at p <= 4 diffusion fits 3 waves/SIMD = 3 resident workgroups per CU.
-constexpr int minw_for(int KIND, int D, int PF = 0)
+constexpr int minw_for(int KIND, int D, int PF = 0, int RB = 1, bool VEC = false)
 {
    if (PF > 0) { return KIND ? (D <= 6 ? 3 : 2) : (D <= 7 ? 4 : 3); }   // streamed pa_data: fewer live registers
+   // D = 5 diffusion fits the 168 VGPRs of three waves per SIMD only in its register-blocked scalar form; the
+   // component loop (VEC) and the one-output-per-thread form (RB = 0: MFEM layout, AddMultPA) spilled 12-96 B per
+   // lane under that cap: two waves for them, no scratch (profiles/r2/d5_spill_probe.txt: BP4 p=4 320 -> 274 us,
+   // BP6 p=4 190 -> 204 us, MFEM-layout BP3 p=4 407 -> 436 us)
+   if (KIND && D == 5 && (VEC || RB == 0)) { return 2; }
    return KIND ? (D <= 5 ? 3 : D <= 7 ? 2 : 1) : (D <= 7 ? 3 : 2);
 }
 
@@ -127,7 +132,7 @@ __device__ __forceinline__ void phase_sync()
 // columns -- held in registers: pa_data is read once for vd components, where the reference
 // stores and reads vd identical copies.  E-vectors are (D,D,D,vd,NE) as in the reference.
 template <int KIND, int D, int Q, int NBZ, bool GATHER, bool ACCUM, bool BLK = false, int ABL = 0, bool PERSIST = true, int PF = 0, int RB = 0, bool VEC = false>
-__global__ void __launch_bounds__(Q*Q*NBZ, minw_for(KIND, D, PF)) MFA_VGPR_CAP
+__global__ void __launch_bounds__(Q*Q*NBZ, minw_for(KIND, D, PF, RB, VEC)) MFA_VGPR_CAP
 k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const BasisTT<D*Q> bg,
            const double *__restrict__ Dq, const double *__restrict__ x,
            const int *__restrict__ gmap, double *__restrict__ yE, const VecArgs va)
@@ -982,6 +987,7 @@ static int apply_pf(int KIND, int D, int Q)
       if (D >= 9) { return Q == D ? 3 : 2; }
       if (D == 8) { return 2; }
       if (D == 6 && Q == 6) { return 3; }
+      if (D == 5 && Q == 8) { return 2; }        // eight whole z-slices do not fit three waves' registers (40-92 B of scratch)
    }
    return 0;
 }
@@ -1077,6 +1083,10 @@ static apply_fn find_apply(int D, int Q)
    MFA_CASE(2, 2) MFA_CASE(2, 3) MFA_CASE(3, 3) MFA_CASE(3, 4) MFA_CASE(4, 4) MFA_CASE(4, 5)
    MFA_CASE(5, 5) MFA_CASE(5, 6) MFA_CASE(6, 6) MFA_CASE(6, 7) MFA_CASE(7, 7) MFA_CASE(7, 8)
    MFA_CASE(8, 8) MFA_CASE(8, 9) MFA_CASE(9, 9) MFA_CASE(9, 10)
+   // the reference's "others" (bilininteg_diffusion_kernels.cpp:62-63, bilininteg_mass_kernels.cpp:59,66-68):
+   // over-integrated rules, e.g. the mass matrix of an order-3 space on an order-3 curved mesh
+   MFA_CASE(4, 6) MFA_CASE(5, 8)
+   if constexpr (KIND == 0) { MFA_CASE(2, 4) MFA_CASE(3, 6) }
 #undef MFA_CASE
    return nullptr;
 }
@@ -1169,6 +1179,10 @@ static apply_vec_fn find_apply_vec(int D, int Q)
    MFA_CASE(2, 2) MFA_CASE(2, 3) MFA_CASE(3, 3) MFA_CASE(3, 4) MFA_CASE(4, 4) MFA_CASE(4, 5)
    MFA_CASE(5, 5) MFA_CASE(5, 6) MFA_CASE(6, 6) MFA_CASE(6, 7) MFA_CASE(7, 7) MFA_CASE(7, 8)
    MFA_CASE(8, 8) MFA_CASE(8, 9) MFA_CASE(9, 9) MFA_CASE(9, 10)
+   // the reference's "others" (bilininteg_diffusion_kernels.cpp:62-63, bilininteg_mass_kernels.cpp:59,66-68):
+   // over-integrated rules, e.g. the mass matrix of an order-3 space on an order-3 curved mesh
+   MFA_CASE(4, 6) MFA_CASE(5, 8)
+   if constexpr (KIND == 0) { MFA_CASE(2, 4) MFA_CASE(3, 6) }
 #undef MFA_CASE
    return nullptr;
 }

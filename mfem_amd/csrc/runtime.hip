@@ -2,6 +2,7 @@
 #include "common.h"
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <mutex>
 #include <set>
 #include <utility>
@@ -52,6 +53,42 @@ void report_fallback(const char *name, int D1D, int Q1D)
       fprintf(stderr, "mfem_amd: fallback kernel %s used for (DIM,D1D,Q1D) = (3,%d,%d)\n",
               name, D1D, Q1D);
    }
+}
+
+// ---- roctx ranges, resolved at run time (common.h TraceRange) ----
+static int g_trace = -1;                       // -1: not looked at yet; 0: off; 1: on
+static int (*g_roctx_push)(const char*) = nullptr;
+static int (*g_roctx_pop)(void) = nullptr;
+
+static void trace_setup()
+{
+   static std::mutex mtx;
+   std::lock_guard<std::mutex> lk(mtx);
+   if (g_trace >= 0) { return; }
+   const char *v = getenv("MFEM_AMD_TRACE");
+   if (!(v && *v && strcmp(v, "0") != 0)) { g_trace = 0; return; }
+   const char *libs[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"};
+   for (const char *name : libs)
+   {
+      void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (!h) { continue; }
+      g_roctx_push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+      g_roctx_pop = reinterpret_cast<int (*)(void)>(dlsym(h, "roctxRangePop"));
+      if (g_roctx_push && g_roctx_pop) { g_trace = 1; return; }
+   }
+   fprintf(stderr, "mfem_amd: MFEM_AMD_TRACE is set but no roctx library could be loaded; ranges are off\n");
+   g_trace = 0;
+}
+
+void trace_push(const char *name)
+{
+   if (g_trace < 0) { trace_setup(); }
+   if (g_trace > 0) { g_roctx_push(name); }
+}
+
+void trace_pop()
+{
+   if (g_trace > 0) { g_roctx_pop(); }
 }
 
 } // namespace mfa

@@ -508,6 +508,7 @@ extern "C" int mfem_amd_pa_setup_from_nodes_3d(int kind, int Dn, int Q1D, int co
                                                double *D, double *detJ_out, void *stream)
 {
    if (ne == 0) { return 0; }
+   const TraceRange range("mfem_amd: PA setup (nodes -> J -> D)");
    MFA_REQUIRE(kind == 0 || kind == 1, "pa_setup_from_nodes_3d: kind must be 0 or 1");
    MFA_REQUIRE(pa_layout == 0 || pa_layout == 1, "pa_setup_from_nodes_3d: pa_layout must be 0 or 1");
    MFA_REQUIRE(coeffDim == 1 || (kind == 1 && (coeffDim == 3 || coeffDim == 6 || coeffDim == 9)),

@@ -419,6 +419,7 @@ static int constrained_mult(const mfem_amd_pa_operator *op, const mfem_amd_comm 
                             double *x, double *y, const double *w, double *partials, int nb,
                             const int *skip, hipStream_t s)
 {
+   const TraceRange range(comm ? "mfem_amd: P^T A P apply" : "mfem_amd: constrained PA apply");
    const bool ess = op->ness > 0;
    MFA_REQUIRE(!ess || op->ess_marker, "pa operator: ess_marker is NULL");
    MFA_REQUIRE(op->yE && op->offsets && op->indices && op->pa_data, "pa operator: null array");
@@ -523,6 +524,7 @@ static int pcg_impl(const mfem_amd_pa_operator *op, const mfem_amd_comm *comm, c
       return 0;
    };
 
+   const TraceRange solve_range(comm ? "mfem_amd: Jacobi-PCG (partitioned)" : "mfem_amd: Jacobi-PCG");
    k_pcg_init<<<dim3(nb), dim3(256), 0, s>>>(n, b, dinv, x, r, d, partials);
    MFA_CHECK_LAUNCH("k_pcg_init");
    if (int rc = global_sum()) { return rc; }
@@ -547,6 +549,7 @@ static int pcg_impl(const mfem_amd_pa_operator *op, const mfem_amd_comm *comm, c
       if (cur.done || launched >= total) { break; }
       int batch = check_every;
       if (batch > total - launched) { batch = total - launched; }
+      const TraceRange batch_range("mfem_amd: PCG iterations (one host poll)");
       for (int k = 0; k < batch; k++)
       {
          k_pcg_update<<<dim3(nb), dim3(256), 0, s>>>(n, st, dinv, r, z, partials);

@@ -16,6 +16,15 @@ CASES = golden_cases()
 TOL = 1e-12
 
 
+EXTRA_SHAPES = [(1, 4, 6), (1, 5, 8), (0, 2, 4), (0, 3, 6), (0, 4, 6), (0, 5, 8)]   # the reference's "others"
+
+
+def registered(kind, D, Q):
+    """MFEM's 3D specialisation lists (bilininteg_diffusion_kernels.cpp:44-63, bilininteg_mass_kernels.cpp:46-68),
+    plus p = 8 -- and (9,9) for diffusion -- which the reference leaves to its fallback"""
+    return (Q in (D, D + 1) and 2 <= D <= 9) or (kind, D, Q) in EXTRA_SHAPES or (kind == 0 and (D, Q) in ((4, 6), (5, 8)))
+
+
 def relerr(a, b):
     return np.max(np.abs(a - b))/max(np.max(np.abs(b)), 1e-300)
 
@@ -133,7 +142,7 @@ def test_apply_and_diag(gh, name):
         else:
             capi.call("mfem_amd_pa_mass_diag_3d", D1, Q1, NE, B, gh.ptr(pad), lay, gh.ptr(dE), None)
         assert relerr(gh.host(dE), c["diagE"]) < TOL
-    assert capi.lib.mfem_amd_has_specialization(c["kind"], D1, Q1) == int(Q1 in (D1, D1 + 1) and 2 <= D1 <= 9)
+    assert capi.lib.mfem_amd_has_specialization(c["kind"], D1, Q1) == int(registered(c["kind"], D1, Q1))
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -236,3 +245,90 @@ def test_errors_are_reported(gh):
     # empty inputs are fine
     capi.call("mfem_amd_restrict_gather", 0, None, None, None, None)
     capi.call("mfem_amd_pa_mass_apply_3d", 3, 4, 0, np.zeros(12), gh.ptr(x), gh.ptr(x), gh.ptr(x), None)
+
+
+def test_trace_ranges_load_and_do_not_change_results(gh):
+    """MFEM_AMD_TRACE=1: the stages of the path are wrapped in roctx ranges (csrc/common.h TraceRange, the role of
+    MFEM_PERF_SCOPE); the roctx library is found at run time and the solve is the same solve."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = (
+        "import sys; sys.path.insert(0, 'tests')\n"
+        "import numpy as np, gpu_helpers as gh\n"
+        "from conftest import golden_cases, load_case\n"
+        "from mfem_amd import capi\n"
+        "capi.call('mfem_amd_init', 0)\n"
+        "c = load_case(golden_cases()[0])\n"
+        "op = gh.DeviceOperator(c, c['ess_tdof'])\n"
+        "n = c['ndofs']; diag, dinv = gh.dev(c['diag']), gh.zeros(n)\n"
+        "capi.call('mfem_amd_jacobi_setup', n, gh.ptr(diag), 1.0, len(c['ess_tdof']), gh.ptr(op.ess), gh.ptr(dinv), None)\n"
+        "X, res, hist = op.pcg(gh.dev(c['B_rhs']), dinv, 1e-10 if c['kind'] == 0 else 1e-6)\n"
+        "assert res.iterations == c['cg_iters'], (res.iterations, c['cg_iters'])\n"
+        "print('traced solve ok', res.iterations)\n")
+    env = dict(os.environ, MFEM_AMD_TRACE="1")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "traced solve ok" in r.stdout
+    assert "ranges are off" not in r.stderr, r.stderr
+
+
+@pytest.mark.parametrize("kind,D,Q", EXTRA_SHAPES)
+def test_extra_registered_shapes(gh, kind, D, Q):
+    """Over-integrated rules (Q1D = D1D + 2, + 3) that MFEM registers beside Q = P+1, P+2: the specialised kernel in
+    both pa_data layouts against the CPU oracle (1e-12), the layouts against each other (bit-identical), the
+    vector-space kernel against the scalar one per component (bit-identical), the diagonal against the oracle."""
+    import oracle_lib as orc
+    from mfem_amd import capi
+    from mfem_amd.cartesian import CartesianProblem
+    assert capi.lib.mfem_amd_has_specialization(kind, D, Q) == 1
+    prob = CartesianProblem(D - 1, 3, 2, 2)
+    ne, ndofs, nd = prob.ne, prob.ndofs, D**3
+    B, G = orc.basis_1d(D - 1, orc.gauss_legendre(Q)[0])
+    nc = 6 if kind else 1
+    pa = 0.5 + splitmix(11, nc*Q**3*ne)
+    x = splitmix(12, ndofs) - 0.5
+    c = dict(kind=kind, D1D=D, Q1D=Q, NE=ne, ndofs=ndofs, B=B, G=G, pa_data=pa, gather_map=prob.gather_map,
+             offsets=prob.offsets, indices=prob.indices)
+    oop = orc.Operator(kind, D, Q, ne, ndofs, B, G, pa, prob.gather_map, prob.offsets, prob.indices)
+    want = oop.mult(x)
+    y0 = gh.host(gh.DeviceOperator(c, layout=0).apply_L2L(gh.dev(x)))
+    op1 = gh.DeviceOperator(c, layout=1)
+    y1 = gh.host(op1.apply_L2L(gh.dev(x)))
+    assert relerr(y0, want) < TOL
+    assert np.array_equal(y0, y1)
+    # E-vector seam (AddMultPA: yE += A xE)
+    xE, yE = gh.zeros(ne*nd), gh.zeros(ne*nd)
+    gm = gh.dev(prob.gather_map, np.int32)
+    capi.call("mfem_amd_restrict_gather", ne*nd, gh.ptr(gm), gh.ptr(gh.dev(x)), gh.ptr(xE), None)
+    if kind:
+        capi.call("mfem_amd_pa_diffusion_apply_3d", D, Q, ne, 1, gh.hB(B), gh.hB(G), gh.ptr(gh.dev(pa)), gh.ptr(xE), gh.ptr(yE), None)
+    else:
+        capi.call("mfem_amd_pa_mass_apply_3d", D, Q, ne, gh.hB(B), gh.ptr(gh.dev(pa)), gh.ptr(xE), gh.ptr(yE), None)
+    # diagonal
+    dE, dL = gh.zeros(ne*nd), gh.zeros(ndofs)
+    if kind:
+        capi.call("mfem_amd_pa_diffusion_diag_3d", D, Q, ne, 1, gh.hB(B), gh.hB(G), gh.ptr(gh.dev(pa)), 0, gh.ptr(dE), None)
+    else:
+        capi.call("mfem_amd_pa_mass_diag_3d", D, Q, ne, gh.hB(B), gh.ptr(gh.dev(pa)), 0, gh.ptr(dE), None)
+    off, ind = gh.dev(prob.offsets, np.int32), gh.dev(prob.indices, np.int32)
+    capi.call("mfem_amd_restrict_scatter", ndofs, gh.ptr(off), gh.ptr(ind), gh.ptr(dE), gh.ptr(dL), 0, 1, None)
+    assert relerr(gh.host(dL), oop.diag()) < TOL
+    # the E-vector of the seam equals the fused kernel's (same arithmetic): compare through E->L
+    yL = gh.zeros(ndofs)
+    capi.call("mfem_amd_restrict_scatter", ndofs, gh.ptr(off), gh.ptr(ind), gh.ptr(yE), gh.ptr(yL), 0, 0, None)
+    assert relerr(gh.host(yL), want) < TOL
+    # vector space, two components byNODES: component c of the vector apply = the scalar apply of component c
+    vd = 2
+    xv = splitmix(13, vd*ndofs) - 0.5
+    yEv = gh.zeros(ne*nd*vd)
+    for lay, pad in ((0, gh.dev(pa)), (1, op1.pa)):
+        capi.call("mfem_amd_pa_apply_L2E_vdim", kind, lay, D, Q, ne, vd, 0, ndofs, gh.hB(B), gh.hB(G), gh.ptr(pad), 0, gh.ptr(gm), None,
+                  gh.ptr(gh.dev(xv)), gh.ptr(yEv), None)
+        got = gh.host(yEv).reshape(ne, vd, nd)
+        for cmp_ in range(vd):
+            sc = gh.DeviceOperator(c, layout=lay)
+            sc.apply_L2L(gh.dev(xv[cmp_*ndofs:(cmp_ + 1)*ndofs]))
+            assert np.array_equal(got[:, cmp_, :].reshape(-1), gh.host(sc.yE))
