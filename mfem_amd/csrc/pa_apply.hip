@@ -55,7 +55,7 @@ constexpr int minw_for(int KIND, int D, int PF = 0, int RB = 1, bool VEC = false
 // so HBM is being read during every phase except the z loop itself.  Issue order matters:
 // vmcnt retires in order, so the (small, needed-first) x gather is issued before the
 // pa_data stream.
-// ABL (tuning builds only, tools/ablate.hip): 0 = the kernel; 1 = memory traffic only (loads +
+// ABL (ablation builds only: -DMFA_ABLATION, tools/ablate.hip): 0 = the kernel; 1 = memory traffic only (loads +
 // stores, no contractions); 2 = contractions only (pa_data not read).  With 2, further bits switch
 // parts of the contractions off (timing only, results meaningless): 512 = basis factors are
 // literals (no scalar loads), 1024 = no z loop, 2048 = no y contraction, 4096 = no transposed y.
@@ -71,9 +71,18 @@ constexpr int minw_for(int KIND, int D, int PF = 0, int RB = 1, bool VEC = false
 // per wave, Q = 8: one), every LDS region of an element is written and read by ONE wave only:
 // the phases need no workgroup barrier, only program order within the wave (LDS instructions of a
 // wave execute in order) -- a compiler-level fence.  MFA_WAVE_SYNC=0 restores the barriers.
-// basis factors as scalar operands (ABL & 512, tuning builds: literals instead)
+// basis factors as scalar operands (ablation builds, ABL & 512: literals instead)
+// MFA_ABLATION (defined by tools/ablate*.hip before they include this file) compiles the ablation branches in;
+// the library is built without it and contains none of them.
+#ifdef MFA_ABLATION
+#define MFA_ABL(mask) ((ABL & (mask)) != 0)
 #define RBB(lo, UP, idx, off) ((ABL & 512) ? (0.25 + 0.0625*(idx)) : bg.lo[(idx) + (off)])
 #define ZBB(lo, idx, off) ((ABL & 512) ? (0.25 + 0.0625*(idx)) : bg.lo[(idx) + (off)])
+#else
+#define MFA_ABL(mask) false
+#define RBB(lo, UP, idx, off) bg.lo[(idx) + (off)]
+#define ZBB(lo, idx, off) bg.lo[(idx) + (off)]
+#endif
 #ifndef MFA_WAVE_SYNC
 #define MFA_WAVE_SYNC 1
 #endif
@@ -188,7 +197,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
       sB[i] = bg.b[i];
       if (KIND) { sG[i] = bg.g[i]; }
    }
-   constexpr bool WS = MFA_WAVE_SYNC && (64 % QQ == 0) && (ABL == 0 || (ABL & 2));
+   constexpr bool WS = MFA_WAVE_SYNC && (64 % QQ == 0) && (ABL == 0 || MFA_ABL(2));
    if (WS) { __syncthreads(); }           // the basis tables are shared by all waves: the only workgroup barrier
 
    static_assert(PF == 0 || (BLK && ABL == 0 && PF < Q), "streamed pa_data needs the blocked layout");
@@ -206,12 +215,14 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
    const int64_t elast = ne - 1;
    auto load_gi = [&](const int64_t e)
    {
+#ifdef MFA_ABLATION
       if (ABL & 8)
       {
 #pragma unroll
          for (int k = 0; k < NXV; k++) { gi[k] = 0; }
          return;
       }
+#endif
       if (GATHER)
       {
          const int *gm = gmap + (e < elast ? e : elast)*D3;
@@ -225,12 +236,14 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
    };
    auto load_xv = [&](const int64_t e, const int cc = 0)
    {
+#ifdef MFA_ABLATION
       if (ABL & 8)
       {
 #pragma unroll
          for (int k = 0; k < NXV; k++) { xv[k] = 1.0; }
          return;
       }
+#endif
       const int64_t ec = e < elast ? e : elast;
       const double *xe = x + (VEC ? ec*va.vd + cc : ec)*D3;
 #pragma unroll
@@ -255,6 +268,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
    };
    auto load_O = [&](const int64_t e, const int64_t bt, const int qz0 = 0, const int qz1 = Q)
    {
+#ifdef MFA_ABLATION
       if (ABL == 2)
       {
 #pragma unroll
@@ -265,6 +279,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
          }
          return;
       }
+#endif
       if (BLK)
       {
          // blocked layout (common.h): whole-workgroup contiguous runs, 16 B per lane
@@ -357,6 +372,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
          if (PERSIST) { load_gi(en); }       // next batch's gather indices: in flight from here
          if (VEC && comp + 1 < va.vd) { load_xv(e, comp + 1); }
          phase_sync<WS>();
+#ifdef MFA_ABLATION
          if (ABL & 1)
          {
             double acc = sX[t2 % D];
@@ -392,6 +408,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
             __syncthreads();
             continue;
          }
+#endif
 
          // --- x contraction: thread (qx = a, dy = b); RB: thread t2 = row (dz,dy), all qx
          int zofs, zx, zy, zt;
@@ -489,11 +506,13 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
                r1[dz] = KIND ? sT[tix(2*D + dz, b, a)] : 0.0;
             }
          }
+#ifdef MFA_ABLATION
          else if (ABL & 2048)
          {
 #pragma unroll
             for (int dz = 0; dz < D; dz++) { r1[dz] = sBX[(dz*D + (b % D))*QP + a]; r2[dz] = r1[dz] + 1.0; r3[dz] = r1[dz] + 2.0; }
          }
+#endif
          else
          {
             double Bb[D], Gb[D];
@@ -528,12 +547,14 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
          double t1[D], t2r[D], t3[D];
 #pragma unroll
          for (int dz = 0; dz < D; dz++) { t1[dz] = 0.0; t2r[dz] = 0.0; t3[dz] = 0.0; }
+#ifdef MFA_ABLATION
          if (ABL & 1024)
          {
 #pragma unroll
             for (int dz = 0; dz < D; dz++) { t1[dz] = r1[dz] + O[dz % Q][0]; t2r[dz] = r2[dz]; t3[dz] = r3[dz]; }
          }
          else
+#endif
 #pragma unroll
          for (int qz = 0; qz < Q; qz++)
          {
@@ -604,6 +625,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
 
          // --- transposed y contraction: thread (qx = a, dy = b); RB: thread t2 = (qx, dz), all dy
          asm volatile("s_mov_b32 %0, 0" : "=s"(zy));
+#ifdef MFA_ABLATION
          if (RB && (ABL & 4096))
          {
             if (t2 < Q*D)
@@ -617,7 +639,9 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
                }
             }
          }
-         else if (RB)
+         else
+#endif
+         if (RB)
          {
             if (t2 < Q*D)
             {

@@ -1,5 +1,6 @@
 // Tuning aid (not part of the product): ablation variants of the BP3 element kernel.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -shared -fPIC tools/ablate.hip mfem_amd/csrc/runtime.hip -o tools/libablate.so
+#define MFA_ABLATION 1   // compile the ablation branches of k_pa_apply in (the library is built without them)
 #include "../mfem_amd/csrc/pa_apply.hip"
 
 template <int D, int Q, int ABL, bool BLK>

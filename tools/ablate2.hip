@@ -2,6 +2,7 @@
 // configuration (one batch per workgroup, register-blocked contractions), pa_data not read (ABL & 2), so the
 // time is the contraction phases' alone.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -shared -fPIC tools/ablate2.hip mfem_amd/csrc/runtime.hip -o tools/libablate2.so
+#define MFA_ABLATION 1   // compile the ablation branches of k_pa_apply in (the library is built without them)
 #include "../mfem_amd/csrc/pa_apply.hip"
 
 template <int KIND, int D, int Q, int ABL, int RB>
