@@ -242,31 +242,43 @@ def make_exchange(part, dev, vdim, rank, world):
     ex_t = Exchange(part, dev, vdim=vdim)
     native, why = None, ""
     mode = os.environ.get("MFEM_AMD_BENCH_TRANSPORT", "native")      # "native-tcp": rehearsal of ranks sharing one GPU
+    torch_name = "torch.distributed all_to_all_single (RCCL)"
+
+    def all_ok(flag):
+        ok = torch.tensor([1.0 if flag else 0.0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        return ok.item() > 0
+
+    # stage 1: every rank builds its side (a rank that cannot must not leave the others waiting in a receive)
     if mode != "torch" and (dist.get_backend() == "nccl" or mode == "native-tcp"):
         try:
             from mfem_amd.comm import NativeExchange, World
             w = World(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")), 23,
                       1 if mode == "native-tcp" else 0)
             native = NativeExchange(w, part, dev, vdim=vdim)
-            nloc = part.prob.ndofs*max(1, vdim)
-            g = torch.Generator(device="cpu"); g.manual_seed(77 + rank)
-            v1 = torch.rand(nloc, dtype=torch.float64, generator=g).to(dev)
-            ghost = torch.from_numpy(native.part.ext_ldof.astype("int64")).to(dev)
-            v1[ghost] = 0.0
-            v2 = v1.clone()
-            native.forward(v1); ex_t.forward(v2)
-            same = bool(torch.equal(v1, v2))
-            native.reverse(v1); ex_t.reverse(v2)
-            torch.cuda.synchronize()
-            if not (same and bool(torch.equal(v1, v2))):
-                raise RuntimeError("native and torch.distributed exchanges disagree")
         except Exception as e:                                               # noqa: BLE001
             native, why = None, f"{type(e).__name__}: {e}"
-    ok = torch.tensor([1.0 if native is not None else 0.0], device=dev)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if ok.item() > 0:
+    if not all_ok(native is not None):
+        return ex_t, torch_name + (f"; native transport not used: {why}" if why else "")
+    # stage 2: one forward and one reverse exchange on both transports, bit for bit
+    nloc = part.prob.ndofs*max(1, vdim)
+    g = torch.Generator(device="cpu"); g.manual_seed(77 + rank)
+    v1 = torch.rand(nloc, dtype=torch.float64, generator=g).to(dev)
+    ghost = torch.from_numpy(native.part.ext_ldof.astype("int64")).to(dev)
+    v1[ghost] = 0.0
+    v2 = v1.clone()
+    same = False
+    try:
+        native.forward(v1); ex_t.forward(v2)
+        same = bool(torch.equal(v1, v2))
+        native.reverse(v1); ex_t.reverse(v2)
+        torch.cuda.synchronize()
+        same = same and bool(torch.equal(v1, v2))
+    except Exception as e:                                                   # noqa: BLE001
+        why = f"{type(e).__name__}: {e}"
+    if all_ok(same):
         return native, ("host-staged TCP (rehearsal)" if mode == "native-tcp" else "RCCL") + " from C++ (libmfem_amd_comm.so), checked against torch.distributed"
-    return ex_t, "torch.distributed all_to_all_single (RCCL)" + (f"; native transport not used: {why}" if why else "")
+    return ex_t, torch_name + "; native transport not used: " + (why or "it disagreed with torch.distributed on a test exchange")
 
 
 def size_row(problem, p, dofs, dev, gen, cg_iters=20):

@@ -19,6 +19,7 @@
 #include <netdb.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <poll.h>
 #include <sys/socket.h>
 #include <unistd.h>
 
@@ -77,10 +78,29 @@ int recv_all(int fd, void *buf, size_t n)
    return 0;
 }
 
+// Sockets of the rendezvous never wait forever: a peer that died before it connected, or that stopped talking,
+// turns into an error on every other rank (the caller falls back or aborts) instead of a hang.
+constexpr int PEER_TIMEOUT_S = 300;
+
 void tune(int fd)
 {
    int one = 1;
    setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+   timeval tv; tv.tv_sec = PEER_TIMEOUT_S; tv.tv_usec = 0;
+   setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+   setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
+}
+
+
+// accept() with a deadline
+int accept_peer(int listen_fd, sockaddr_in *pa, int seconds)
+{
+   pollfd pf; pf.fd = listen_fd; pf.events = POLLIN; pf.revents = 0;
+   const int rc = ::poll(&pf, 1, seconds*1000);
+   if (rc == 0) { errno = ETIMEDOUT; return -1; }
+   if (rc < 0) { return -1; }
+   socklen_t len = sizeof(sockaddr_in);
+   return pa ? ::accept(listen_fd, (sockaddr*)pa, &len) : ::accept(listen_fd, nullptr, nullptr);
 }
 
 int listen_on(int port, int *fd_out, int *port_out)
@@ -187,9 +207,9 @@ extern "C" int mfem_amd_world_create(int rank, int size, const char *addr, int p
          std::vector<uint32_t> peer_addr((size_t)size, 0), peer_port((size_t)size, 0);
          for (int k = 1; k < size; k++)
          {
-            sockaddr_in pa; socklen_t len = sizeof pa;
-            const int fd = ::accept(w->listen_fd, (sockaddr*)&pa, &len);
-            if (fd < 0) { delete w; return fail("accept: %s", strerror(errno)); }
+            sockaddr_in pa;
+            const int fd = accept_peer(w->listen_fd, &pa, 120);
+            if (fd < 0) { delete w; return fail("accept (%d of %d ranks have not connected within 120 s): %s", size - k, size, strerror(errno)); }
             tune(fd);
             int32_t hello[2];
             if (recv_all(fd, hello, sizeof hello)) { delete w; return 1; }
@@ -234,8 +254,8 @@ extern "C" int mfem_amd_world_create(int rank, int size, const char *addr, int p
             }
             for (int k = rank + 1; k < size; k++)
             {
-               const int fd = ::accept(w->listen_fd, nullptr, nullptr);
-               if (fd < 0) { delete w; return fail("accept: %s", strerror(errno)); }
+               const int fd = accept_peer(w->listen_fd, nullptr, 120);
+               if (fd < 0) { delete w; return fail("accept (peer ranks above %d): %s", rank, strerror(errno)); }
                tune(fd);
                int32_t who = -1;
                if (recv_all(fd, &who, sizeof who)) { delete w; return 1; }
