@@ -133,10 +133,16 @@ int main(int argc, char **argv)
       Device device("hip");
       ConstantCoefficient one(1.0);
       FunctionCoefficient fc(coef_fn);
-      Coefficient &Q = varcoef ? (Coefficient&)fc : (Coefficient&)one;
+      // <varcoef> 7: the same function, handed over as its values at the quadrature points (QuadratureFunctionCoefficient)
+      const bool qfmode = atoi(argv[a+3]) == 7;
+      QuadratureSpace qspace(*mesh, *ir);
+      QuadratureFunction qfun(&qspace);
+      if (qfmode) { fc.Project(qfun); }
+      QuadratureFunctionCoefficient qfc(qfun);
+      Coefficient &Q = qfmode ? (Coefficient&)qfc : varcoef ? (Coefficient&)fc : (Coefficient&)one;
       // <varcoef> 2..6: diffusion with a vector function / symmetric matrix constant / symmetric matrix
       // function / matrix constant / matrix function coefficient (the cases of tests/golden/mat)
-      const int ctype = atoi(argv[a+3]) - 2;
+      const int ctype = qfmode ? -1 : atoi(argv[a+3]) - 2;
       Vector mid(3); mid(0) = 0.4; mid(1) = 0.3; mid(2) = 0.6;
       DenseSymmetricMatrix Ks; sym_fn(mid, Ks);
       DenseMatrix Km; mat_fn(mid, Km);
@@ -149,7 +155,7 @@ int main(int argc, char **argv)
       const bool nonsym = ctype >= 3;
       BilinearForm bf(&fes);
       bf.SetAssemblyLevel(AssemblyLevel::PARTIAL);
-      const IntegrationRule *irp = rule == 2 ? nullptr : ir;
+      const IntegrationRule *irp = (rule == 2 && !qfmode) ? nullptr : ir;
       BilinearFormIntegrator *bfi = (kind == 0) ? (BilinearFormIntegrator*)new MassIntegrator(Q, irp)
                                     : ctype == 0 ? (BilinearFormIntegrator*)new DiffusionIntegrator(vq, irp)
                                     : ctype > 0 ? (BilinearFormIntegrator*)new DiffusionIntegrator(*MQs[ctype], irp)

@@ -33,8 +33,10 @@ namespace mfa
 
 // Register budget hint (waves per SIMD the kernel should fit, 2nd __launch_bounds__ argument
 // on AMD): at p <= 4 diffusion fits 3 waves/SIMD = 3 resident workgroups per CU.
-constexpr int minw_for(int KIND, int D, int PF = 0, int RB = 1, bool VEC = false)
+constexpr int minw_for(int KIND, int D, int PF = 0, int RB = 1, bool VEC = false, int Q = 0)
 {
+   // (5,8): only the dispatched form (two z-slices streamed) fits three waves; the override-only forms get two
+   if (KIND && D == 5 && Q >= 8 && PF != 2) { return 2; }
    if (PF > 0) { return KIND ? (D <= 6 ? 3 : 2) : (D <= 7 ? 4 : 3); }   // streamed pa_data: fewer live registers
    // D = 5 diffusion fits the 168 VGPRs of three waves per SIMD only in its register-blocked scalar form; the
    // component loop (VEC) and the one-output-per-thread form (RB = 0: MFEM layout, AddMultPA) spilled 12-96 B per
@@ -141,7 +143,7 @@ __device__ __forceinline__ void phase_sync()
 // columns -- held in registers: pa_data is read once for vd components, where the reference
 // stores and reads vd identical copies.  E-vectors are (D,D,D,vd,NE) as in the reference.
 template <int KIND, int D, int Q, int NBZ, bool GATHER, bool ACCUM, bool BLK = false, int ABL = 0, bool PERSIST = true, int PF = 0, int RB = 0, bool VEC = false>
-__global__ void __launch_bounds__(Q*Q*NBZ, minw_for(KIND, D, PF, RB, VEC)) MFA_VGPR_CAP
+__global__ void __launch_bounds__(Q*Q*NBZ, minw_for(KIND, D, PF, RB, VEC, Q)) MFA_VGPR_CAP
 k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const BasisTT<D*Q> bg,
            const double *__restrict__ Dq, const double *__restrict__ x,
            const int *__restrict__ gmap, double *__restrict__ yE, const VecArgs va)

@@ -423,6 +423,19 @@ void eval_coefficient(Mesh &mesh, const IntegrationRule &ir, Coefficient *Q, Vec
       C.SetSize(1); C.HostWrite()[0] = cval; const_c = 1;
       return;
    }
+   if (!MQ && !VQ)
+   {
+      if (const QuadratureFunctionCoefficient *qc = dynamic_cast<const QuadratureFunctionCoefficient*>(Q))
+      {
+         // values already at the quadrature points (fem/coefficient.cpp:1992-1995): used where they are, on the device
+         const QuadratureFunction &qf = qc->GetQuadFunction();
+         MFEM_VERIFY(qf.GetSpace()->GetMesh() == &mesh && qf.GetSpace()->GetIntRule().GetNPoints() == ir.GetNPoints() &&
+                     qf.GetSpace()->GetIntRule().n1d == ir.n1d && qf.GetSpace()->GetIntRule().quad_type == ir.quad_type,
+                     "mfem_amd: the QuadratureFunction lives on another mesh or integration rule than the integrator's");
+         C = qf; const_c = 0;
+         return;
+      }
+   }
    const_c = 0;
    std::vector<real_t> xe;
    const int Dn = internal::ElementNodesLex(mesh, xe);
@@ -447,6 +460,23 @@ void eval_coefficient(Mesh &mesh, const IntegrationRule &ir, Coefficient *Q, Vec
       }
    }
 }
+}
+
+// ---- quadrature spaces and functions ----
+QuadratureSpace::QuadratureSpace(Mesh *m, int order_) : mesh(m), ir(&IntRules.Get(Geometry::CUBE, order_)), order(order_)
+{ MFEM_VERIFY(m && m->Dimension() == 3, "mfem_amd: quadrature spaces on hexahedral meshes"); }
+QuadratureSpace::QuadratureSpace(Mesh &m, const IntegrationRule &ir_) : mesh(&m), ir(&ir_), order(ir_.GetOrder())
+{ MFEM_VERIFY(ir_.n1d > 0, "mfem_amd: quadrature spaces take tensor rules (IntRules.Get(Geometry::CUBE, order))"); }
+int QuadratureSpace::GetNE() const { return mesh->GetNE(); }
+
+void Coefficient::Project(QuadratureFunction &qf)
+{
+   MFEM_VERIFY(qf.GetVDim() == 1, "Coefficient::Project: QuadratureFunction's vdim must be 1");
+   real_t cval;
+   if (IsConstant(cval)) { qf = cval; return; }
+   Vector C; int const_c = 0;
+   eval_coefficient(*qf.GetSpace()->GetMesh(), qf.GetSpace()->GetIntRule(), this, C, const_c);
+   qf = C;
 }
 
 // ---- LinearForm (fem/linearform.cpp Assemble; device kernel of lininteg_domain.cpp:22-59) --

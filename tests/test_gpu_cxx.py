@@ -136,6 +136,27 @@ def test_cxx_api_matches_reference_outputs(name, tmp_path):
     assert np.all(np.abs(h[big] - h0[big]) <= 1e-5*h0[big])      # the reference printed 6 digits
 
 
+@pytest.mark.parametrize("name", [n for n in golden_cases() if int(load_case(n)["varcoef"])])
+def test_cxx_quadrature_function_coefficient(name, tmp_path):
+    """QuadratureFunctionCoefficient (fem/coefficient.hpp:2432-2460; CoefficientVector::Project references its values,
+    fem/coefficient.cpp:1992-1995): the variable coefficient of the reference's cases handed over as values at the
+    quadrature points (Coefficient::Project(QuadratureFunction&), then the device-resident array straight into the PA
+    setup kernel) reproduces the reference's operator, diagonal and solve like the FunctionCoefficient itself."""
+    c = load_case(name)
+    spec = spec_for(name, c)
+    if spec is None:
+        pytest.skip("legacy (Cubic) nodal collection")
+    out = subprocess.run([str(BIN / "dump_tables"), str(tmp_path)] + spec + ["7", "run"],
+                         capture_output=True, text=True, timeout=300, cwd=str(ROOT))
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    r = {f.stem: np.fromfile(f, dtype=np.int32 if f.suffix == ".i32" else np.float64) for f in tmp_path.iterdir()}
+    for k in ["y", "yE", "diag", "diagE", "y_constrained", "jacobi_x"]:
+        assert _rel(r[k], c[k]) < 1e-12, (k, _rel(r[k], c[k]))
+    its, conv = r["cg_iters"][:2]
+    assert (its, conv) == (int(c["cg_iters"]), int(c["cg_converged"]))
+    assert _rel(r["X"], c["X"]) < 1e-9
+
+
 # ---- DiffusionIntegrator with vector / matrix coefficients through the C++ classes ----------
 from test_oracle_matcoef import CASES as MAT_CASES, load_mat          # noqa: E402
 
