@@ -4,8 +4,13 @@
  * order of the reference's host execution).  Only tests/, __graft_entry__.smoke() and
  * bench.py's cpu_baseline leg may load this library; the product (mfem_amd/) never does.
  *
- * Pinned against: the tests/golden npz files (arrays dumped from the reference itself, see
+ * Checked against: the tests/golden npz files (arrays dumped from the reference itself, see
  * oracle/ref_dump.cpp) and the known-answer table in BASELINE.md section 2.
+ * PARITY UNPINNED by this build's rules: those arrays came from a serial libmfem.a that the survey stage had
+ * produced with the reference's own build system (cmake + generated config/_config.hpp); the reference cannot
+ * be built from its sources alone here, it holds no golden vectors of its own for this path, and the
+ * generating binary is gone -- the fixtures are kept, not reproducible.  The independent dense assembly of
+ * tests/full_assembly.py (the reference's own test method, PA == assembled matrix) is the second check.
  *
  * Every function cites the reference file:line it follows (paths relative to the
  * reference root).  All sizes that can exceed 2^31 are int64_t.
