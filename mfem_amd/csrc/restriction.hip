@@ -131,7 +131,7 @@ __device__ __forceinline__ void scatter_rows(const int64_t ndofs, const int *__r
 // order.  Blocks with more than CAP entries (vertex and edge rows of MFEM's numbering) go through in four
 // 256-row parts; a part that still does not fit (valence > CAP/256) is summed straight from memory.
 constexpr int SCAT_CAP = 3072;
-template <int MODE, bool DOT>
+template <int MODE, bool DOT, bool NT = false>
 __device__ __forceinline__ void scatter_block_rows(const int64_t ndofs, const int *__restrict__ offsets,
                                                    const int *__restrict__ indices, const double *__restrict__ xE,
                                                    double *__restrict__ y, const unsigned char *__restrict__ marker,
@@ -148,12 +148,20 @@ __device__ __forceinline__ void scatter_block_rows(const int64_t ndofs, const in
 #pragma unroll
       for (int k = 0; k < K; k++)
       {
-         if (256*k < cnt) { const int e = t + 256*k; id[k] = indices[e_lo + (e < cnt ? e : cnt - 1)]; }
+         if (256*k < cnt)
+         {
+            const int e = t + 256*k;
+            const int *ip = &indices[e_lo + (e < cnt ? e : cnt - 1)];
+            id[k] = NT ? __builtin_nontemporal_load(ip) : *ip;
+         }
       }
 #pragma unroll
       for (int k = 0; k < K; k++)
       {
-         if (256*k < cnt) { v[k] = xE[id[k] >= 0 ? id[k] : -1 - id[k]]; }
+         if (256*k < cnt)
+         {
+            v[k] = xE[id[k] >= 0 ? id[k] : -1 - id[k]];       // re-used across the four sweeps of the numbering: cached
+         }
       }
 #pragma unroll
       for (int k = 0; k < K; k++)
@@ -235,7 +243,7 @@ __device__ __forceinline__ void scatter_block_rows(const int64_t ndofs, const in
             double r = val[j];
             if (mk[j]) { r = (mk[j] == 1) ? xin[i] : 0.0; }
             if (MODE == 1) { r += y[i]; }
-            y[i] = r;
+            if (NT) { __builtin_nontemporal_store(r, &y[i]); } else { y[i] = r; }
             if (DOT) { prod += wv[j]*r; }
          }
       }
@@ -262,7 +270,8 @@ k_scatter(const int64_t ndofs, const int *__restrict__ offsets,
    const int64_t bid = (flags & 1) ? xcd_remap(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
    if (!(flags & 2) && nnz < 6*ndofs && !(flags & 1))
    {
-      scatter_block_rows<MODE, DOT>(ndofs, offsets, indices, xE, y, marker, xin, w, prod, sval);
+      if (flags & 4) { scatter_block_rows<MODE, DOT, true>(ndofs, offsets, indices, xE, y, marker, xin, w, prod, sval); }
+      else { scatter_block_rows<MODE, DOT>(ndofs, offsets, indices, xE, y, marker, xin, w, prod, sval); }
    }
    else if (nnz >= 3*ndofs) { scatter_rows<MODE, DOT, 8, 2>(ndofs, offsets, indices, xE, y, marker, xin, w, prod, bid); }
    else if (20*nnz >= 31*ndofs) { scatter_rows<MODE, DOT, 4, 4>(ndofs, offsets, indices, xE, y, marker, xin, w, prod, bid); }
@@ -629,7 +638,8 @@ static inline unsigned grid_for(int64_t n) { return (unsigned)((n + 255)/256); }
 static int scatter_flags()
 {
    static const int v = ((getenv("MFEM_AMD_SCATTER_XCD") && atoi(getenv("MFEM_AMD_SCATTER_XCD"))) ? 1 : 0) |
-                        ((getenv("MFEM_AMD_SCATTER_BLK") && !atoi(getenv("MFEM_AMD_SCATTER_BLK"))) ? 2 : 0);
+                        ((getenv("MFEM_AMD_SCATTER_BLK") && !atoi(getenv("MFEM_AMD_SCATTER_BLK"))) ? 2 : 0) |
+                        ((getenv("MFEM_AMD_SCATTER_NT") && !atoi(getenv("MFEM_AMD_SCATTER_NT"))) ? 0 : 4);
    return v;
 }
 
