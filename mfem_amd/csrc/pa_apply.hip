@@ -26,6 +26,7 @@
 //  * Logical block ids are remapped so every XCD (private L2) works on one contiguous
 //    element range.
 #include "common.h"
+#include <type_traits>
 #include <cstdlib>
 
 namespace mfa
@@ -42,7 +43,7 @@ constexpr int minw_for(int KIND, int D, int PF = 0, int RB = 1, bool VEC = false
    // component loop (VEC) and the one-output-per-thread form (RB = 0: MFEM layout, AddMultPA) spilled 12-96 B per
    // lane under that cap: two waves for them, no scratch (profiles/r2/d5_spill_probe.txt: BP4 p=4 320 -> 274 us,
    // BP6 p=4 190 -> 204 us, MFEM-layout BP3 p=4 407 -> 436 us)
-   if (KIND && D == 5 && (VEC || RB == 0)) { return 2; }
+   if (KIND && D == 5 && (VEC || RB == 0 || (RB == 2 && Q == 6))) { return 2; }   // (5,6) RB = 2: override-only form
    return KIND ? (D <= 5 ? 3 : D <= 7 ? 2 : 1) : (D <= 7 ? 3 : 2);
 }
 
@@ -92,17 +93,15 @@ constexpr int minw_for(int KIND, int D, int PF = 0, int RB = 1, bool VEC = false
 #ifndef MFA_ONLY_D
 #define MFA_ONLY_D 0
 #endif
-// pa_data is read exactly once per application; where it measured faster (profiles/r2/nt_probe.txt: mass p >= 5
-// 4-7 %, collocated diffusion p = 1, 3 4-5 %, BP3 p = 6 3 %; 1-2.5 % slower for BP3 p <= 4) it is loaded with the
-// non-temporal policy, which keeps the L2 for the gathered x values.  MFA_NT=0|1 forces it off / on (tuning builds).
-constexpr bool nt_table(int KIND, int D, int Q)
-{
-#ifdef MFA_NT
-   return MFA_NT != 0;
-#else
-   return KIND == 0 ? D >= 6 : ((Q == D && D <= 4) || (Q > D && D == 7));
-#endif
-}
+// pa_data is read exactly once per application.  When it is larger than the Infinity Cache it is loaded with the
+// non-temporal policy, which leaves the caches to what IS re-used -- the gathered x values, the gather map and the
+// E-vector lines the E->L kernel re-reads.  Timed where it matters, in the alternating sequence of the two apply
+// kernels (profiles/r2/pa_nt_in_context.txt): BP3 p = 2..5 4.3 / 4.0 / 3.4 / 1.6 % faster than cached loads, BP5
+// p = 4, 6 2.5 / 4 %, BP1 p = 4 2.8 %, nowhere slower at 1e7 dofs; the kernel timed in a loop of its own had suggested
+// a per-shape table (profiles/r2/nt_probe.txt).  A pa_data that fits the cache (1e6 dofs: 160 MB at BP3 p = 4) is
+// better left in it between applications (5 % at 1e6 dofs).  The launcher decides (bit 4 of `sched`);
+// MFEM_AMD_APPLY_NT=0|1 forces it (tuning aid).
+constexpr int SCHED_NT = 16;
 template <bool NT> __device__ __forceinline__ double load_pa(const double *p)
 {
    return NT ? __builtin_nontemporal_load(p) : *p;
@@ -180,10 +179,10 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
    // (workgroup w takes batches w, w+G, ...: at any time the grid works on G consecutive
    // batches, so the chip reads/writes one moving window of memory, like a streaming copy)
    // PERSIST = false: one batch per workgroup (grid = nbatches), nothing prefetched.
-   const int SCHED = PERSIST ? sched : 1;
+   const int SCHED = PERSIST ? (sched & 15) : 1;
    const int64_t G_ = gridDim.x;
    // one batch per workgroup with sched == 2: workgroups b, b+8, ... (one XCD, one L2) take consecutive batches
-   const int64_t L = (PERSIST ? SCHED != 0 : sched != 2) ? (int64_t)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+   const int64_t L = (PERSIST ? SCHED != 0 : (sched & 15) != 2) ? (int64_t)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
    const int64_t b0 = SCHED ? L : (L*nbatches)/G_;
    const int64_t b1 = SCHED ? nbatches : ((L + 1)*nbatches)/G_;
    const int64_t bstep = SCHED ? G_ : 1;
@@ -232,7 +231,10 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
          for (int k = 0; k < NXV; k++)
          {
             const int i = t2 + k*QQ;
-            gi[k] = gm[i < D3 ? i : D3 - 1];
+            // the gather map is read once per application too: same policy as pa_data (BP3 p = 5 4.6 %, BP1 p = 5..7 4 %
+            // on the apply, profiles/r2/pa_nt_in_context.txt)
+            const int *gp = &gm[i < D3 ? i : D3 - 1];
+            gi[k] = (sched & SCHED_NT) ? __builtin_nontemporal_load(gp) : *gp;
          }
       }
    };
@@ -285,28 +287,33 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
       if (BLK)
       {
          // blocked layout (common.h): whole-workgroup contiguous runs, 16 B per lane
-         if (KIND)
+         auto columns = [&](auto ntc)
          {
-            const double2 *Db = reinterpret_cast<const double2*>(Dq + (VEC ? comp*va.d_comp_stride : 0))
-                                + bt*(int64_t)(3*Q*NBZ*QQ) + tz*QQ + b*Q + a;
-#pragma unroll
-            for (int qz = 0; qz < Q; qz++)
+            constexpr bool NT = decltype(ntc)::value;
+            if (KIND)
             {
-               if (qz < qz0 || qz >= qz1) { continue; }
+               const double2 *Db = reinterpret_cast<const double2*>(Dq + (VEC ? comp*va.d_comp_stride : 0))
+                                   + bt*(int64_t)(3*Q*NBZ*QQ) + tz*QQ + b*Q + a;
 #pragma unroll
-               for (int cp = 0; cp < 3; cp++)
+               for (int qz = 0; qz < Q; qz++)
                {
-                  const double2 v = load_pa<nt_table(KIND, D, Q)>(&Db[(qz*3 + cp)*(NBZ*QQ)]);
-                  O[qz][(2*cp) % NC] = v.x; O[qz][(2*cp + 1) % NC] = v.y;
+                  if (qz < qz0 || qz >= qz1) { continue; }
+#pragma unroll
+                  for (int cp = 0; cp < 3; cp++)
+                  {
+                     const double2 v = load_pa<NT>(&Db[(qz*3 + cp)*(NBZ*QQ)]);
+                     O[qz][(2*cp) % NC] = v.x; O[qz][(2*cp + 1) % NC] = v.y;
+                  }
                }
             }
-         }
-         else
-         {
-            const double *Db = Dq + (VEC ? comp*va.d_comp_stride : 0) + bt*(int64_t)(Q*NBZ*QQ) + tz*QQ + b*Q + a;
+            else
+            {
+               const double *Db = Dq + (VEC ? comp*va.d_comp_stride : 0) + bt*(int64_t)(Q*NBZ*QQ) + tz*QQ + b*Q + a;
 #pragma unroll
-            for (int qz = 0; qz < Q; qz++) { if (qz >= qz0 && qz < qz1) { O[qz][0] = load_pa<nt_table(KIND, D, Q)>(&Db[qz*(NBZ*QQ)]); } }
-         }
+               for (int qz = 0; qz < Q; qz++) { if (qz >= qz0 && qz < qz1) { O[qz][0] = load_pa<NT>(&Db[qz*(NBZ*QQ)]); } }
+            }
+         };
+         if (sched & SCHED_NT) { columns(std::true_type{}); } else { columns(std::false_type{}); }
          return;
       }
       const int64_t ec = e < elast ? e : elast;
@@ -324,6 +331,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
    // one z-slice of the blocked pa_data of batch bt (PF > 0)
    auto load_slice = [&](const int64_t bt, const int qz, double (&dst)[NC])
    {
+      // (plain loads: a policy switch inside the streaming ring cost the (8,9) / (9,10) kernels 15-30 %)
       if (KIND)
       {
          const double2 *Db = reinterpret_cast<const double2*>(Dq) + bt*(int64_t)(3*Q*NBZ*QQ) + tz*QQ + b*Q + a;
@@ -1040,6 +1048,20 @@ static int apply_rb(int KIND, int D, int Q)
    return rb_table(KIND, D, Q);
 }
 
+// SCHED_NT for a blocked pa_data of `bytes`: non-temporal once it cannot stay in the 256 MiB Infinity Cache beside
+// the vectors and index tables of the application
+static int apply_nt(int64_t bytes)
+{
+   static int forced = -2;
+   if (forced == -2)
+   {
+      const char *v = getenv("MFEM_AMD_APPLY_NT");
+      forced = (v && (*v == '0' || *v == '1')) ? (*v - '0') : -1;
+   }
+   if (forced >= 0) { return forced ? SCHED_NT : 0; }
+   return bytes > ((int64_t)192 << 20) ? SCHED_NT : 0;
+}
+
 template <int KIND, int D, int Q, bool GATHER, bool ACCUM, bool BLK, int PF = 0, int RB = 0, bool RESOLVED = false>
 static int launch_apply(int64_t ne, const double *B, const double *G, const double *Dq,
                         const double *x, const int *gmap, double *yE, hipStream_t s)
@@ -1086,16 +1108,17 @@ static int launch_apply(int64_t ne, const double *B, const double *G, const doub
    fill_basis(bg, D, Q, B, G);
    const int64_t nb = (ne + NBZ - 1)/NBZ;
    if (nb == 0) { return 0; }
+   const int nt = BLK ? apply_nt((int64_t)sizeof(double)*blocked_size(KIND, Q, ne)) : 0;
    if (mode == 0)
    {
       MFA_REQUIRE(nb < (int64_t)2147483647, "pa_apply: too many workgroups (%lld)", (long long)nb);
       static const int xcd = (getenv("MFEM_AMD_APPLY_XCD") && atoi(getenv("MFEM_AMD_APPLY_XCD"))) ? 2 : 1;
-      kern1<<<dim3((unsigned)nb), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, xcd, bg, Dq, x, gmap, yE, VecArgs{});
+      kern1<<<dim3((unsigned)nb), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, xcd | nt, bg, Dq, x, gmap, yE, VecArgs{});
    }
    else
    {
       const unsigned grid = (unsigned)(nb < resident[dev] ? nb : resident[dev]);
-      kern<<<dim3(grid), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, mode == 2 ? 1 : 0, bg, Dq, x, gmap, yE, VecArgs{});
+      kern<<<dim3(grid), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, (mode == 2 ? 1 : 0) | nt, bg, Dq, x, gmap, yE, VecArgs{});
    }
    MFA_CHECK_LAUNCH("k_pa_apply");
    return 0;
@@ -1192,7 +1215,8 @@ static int launch_apply_vec(int64_t ne, const double *B, const double *G, const 
    const int64_t nb = (ne + NBZ - 1)/NBZ;
    if (nb == 0) { return 0; }
    MFA_REQUIRE(nb < (int64_t)2147483647, "pa_apply: too many workgroups (%lld)", (long long)nb);
-   kern<<<dim3((unsigned)nb), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, 1, bg, Dq, x, gmap, yE, va);
+   const int nt = BLK ? apply_nt((int64_t)sizeof(double)*blocked_size(KIND, Q, ne)*(va.d_comp_stride ? va.vd : 1)) : 0;
+   kern<<<dim3((unsigned)nb), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, 1 | nt, bg, Dq, x, gmap, yE, va);
    MFA_CHECK_LAUNCH("k_pa_apply (vector)");
    return 0;
 }

@@ -270,7 +270,9 @@ k_scatter(const int64_t ndofs, const int *__restrict__ offsets,
    const int64_t bid = (flags & 1) ? xcd_remap(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
    if (!(flags & 2) && nnz < 6*ndofs && !(flags & 1))
    {
-      if (flags & 4) { scatter_block_rows<MODE, DOT, true>(ndofs, offsets, indices, xE, y, marker, xin, w, prod, sval); }
+      // streamed-once operands non-temporal when the tables cannot stay in the Infinity Cache between applications
+      // anyway (profiles/r2/e2l_nt_probe.txt); small problems keep everything cached
+      if ((flags & 4) && ndofs > 3000000) { scatter_block_rows<MODE, DOT, true>(ndofs, offsets, indices, xE, y, marker, xin, w, prod, sval); }
       else { scatter_block_rows<MODE, DOT>(ndofs, offsets, indices, xE, y, marker, xin, w, prod, sval); }
    }
    else if (nnz >= 3*ndofs) { scatter_rows<MODE, DOT, 8, 2>(ndofs, offsets, indices, xE, y, marker, xin, w, prod, bid); }
