@@ -93,15 +93,16 @@ constexpr int minw_for(int KIND, int D, int PF = 0, int RB = 1, bool VEC = false
 #ifndef MFA_ONLY_D
 #define MFA_ONLY_D 0
 #endif
-// pa_data is read exactly once per application.  When it is larger than the Infinity Cache it is loaded with the
-// non-temporal policy, which leaves the caches to what IS re-used -- the gathered x values, the gather map and the
-// E-vector lines the E->L kernel re-reads.  Timed where it matters, in the alternating sequence of the two apply
-// kernels (profiles/r2/pa_nt_in_context.txt): BP3 p = 2..5 4.3 / 4.0 / 3.4 / 1.6 % faster than cached loads, BP5
-// p = 4, 6 2.5 / 4 %, BP1 p = 4 2.8 %, nowhere slower at 1e7 dofs; the kernel timed in a loop of its own had suggested
-// a per-shape table (profiles/r2/nt_probe.txt).  A pa_data that fits the cache (1e6 dofs: 160 MB at BP3 p = 4) is
-// better left in it between applications (5 % at 1e6 dofs).  The launcher decides (bit 4 of `sched`);
-// MFEM_AMD_APPLY_NT=0|1 forces it (tuning aid).
-constexpr int SCHED_NT = 16;
+// pa_data and the gather map are read exactly once per application.  When pa_data is larger than the Infinity Cache
+// both are loaded with the non-temporal policy (template argument NTP), which leaves the caches to what IS re-used --
+// the gathered x values and the E-vector lines the E->L kernel re-reads.  Timed where it matters, in the alternating
+// sequence of the two apply kernels (profiles/r2/pa_nt_in_context.txt): BP3 p = 2..5 4.3 / 4.0 / 3.4 / 1.6 % faster
+// than cached loads for pa_data and another 4.6 % at p = 5 for the map, BP1 p = 5..7 4 %, nowhere slower at 1e7 dofs;
+// the kernel timed in a loop of its own had suggested a per-shape table (profiles/r2/nt_probe.txt).  A pa_data that
+// fits the cache (1e6 dofs: 160 MB at BP3 p = 4) is better left in it between applications (5 %), so the launcher
+// picks the instantiation by size; a run-time switch inside the kernel cost what the policy gains (3 % at p = 3, 4).
+// The streamed (PF > 0) kernels keep cached loads: non-temporal slices cost (8,9) / (9,10) 15-30 %.
+// MFEM_AMD_APPLY_NT=0|1 forces the choice (tuning aid).
 template <bool NT> __device__ __forceinline__ double load_pa(const double *p)
 {
    return NT ? __builtin_nontemporal_load(p) : *p;
@@ -141,7 +142,7 @@ __device__ __forceinline__ void phase_sync()
 // indices -- and, when all components share one pa_data (scalar coefficient), the pa_data
 // columns -- held in registers: pa_data is read once for vd components, where the reference
 // stores and reads vd identical copies.  E-vectors are (D,D,D,vd,NE) as in the reference.
-template <int KIND, int D, int Q, int NBZ, bool GATHER, bool ACCUM, bool BLK = false, int ABL = 0, bool PERSIST = true, int PF = 0, int RB = 0, bool VEC = false>
+template <int KIND, int D, int Q, int NBZ, bool GATHER, bool ACCUM, bool BLK = false, int ABL = 0, bool PERSIST = true, int PF = 0, int RB = 0, bool VEC = false, bool NTP = false>
 __global__ void __launch_bounds__(Q*Q*NBZ, minw_for(KIND, D, PF, RB, VEC, Q)) MFA_VGPR_CAP
 k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const BasisTT<D*Q> bg,
            const double *__restrict__ Dq, const double *__restrict__ x,
@@ -179,10 +180,10 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
    // (workgroup w takes batches w, w+G, ...: at any time the grid works on G consecutive
    // batches, so the chip reads/writes one moving window of memory, like a streaming copy)
    // PERSIST = false: one batch per workgroup (grid = nbatches), nothing prefetched.
-   const int SCHED = PERSIST ? (sched & 15) : 1;
+   const int SCHED = PERSIST ? sched : 1;
    const int64_t G_ = gridDim.x;
    // one batch per workgroup with sched == 2: workgroups b, b+8, ... (one XCD, one L2) take consecutive batches
-   const int64_t L = (PERSIST ? SCHED != 0 : (sched & 15) != 2) ? (int64_t)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+   const int64_t L = (PERSIST ? SCHED != 0 : sched != 2) ? (int64_t)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
    const int64_t b0 = SCHED ? L : (L*nbatches)/G_;
    const int64_t b1 = SCHED ? nbatches : ((L + 1)*nbatches)/G_;
    const int64_t bstep = SCHED ? G_ : 1;
@@ -234,7 +235,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
             // the gather map is read once per application too: same policy as pa_data (BP3 p = 5 4.6 %, BP1 p = 5..7 4 %
             // on the apply, profiles/r2/pa_nt_in_context.txt)
             const int *gp = &gm[i < D3 ? i : D3 - 1];
-            gi[k] = (sched & SCHED_NT) ? __builtin_nontemporal_load(gp) : *gp;
+            gi[k] = NTP ? __builtin_nontemporal_load(gp) : *gp;
          }
       }
    };
@@ -287,33 +288,28 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
       if (BLK)
       {
          // blocked layout (common.h): whole-workgroup contiguous runs, 16 B per lane
-         auto columns = [&](auto ntc)
+         if (KIND)
          {
-            constexpr bool NT = decltype(ntc)::value;
-            if (KIND)
+            const double2 *Db = reinterpret_cast<const double2*>(Dq + (VEC ? comp*va.d_comp_stride : 0))
+                                + bt*(int64_t)(3*Q*NBZ*QQ) + tz*QQ + b*Q + a;
+#pragma unroll
+            for (int qz = 0; qz < Q; qz++)
             {
-               const double2 *Db = reinterpret_cast<const double2*>(Dq + (VEC ? comp*va.d_comp_stride : 0))
-                                   + bt*(int64_t)(3*Q*NBZ*QQ) + tz*QQ + b*Q + a;
+               if (qz < qz0 || qz >= qz1) { continue; }
 #pragma unroll
-               for (int qz = 0; qz < Q; qz++)
+               for (int cp = 0; cp < 3; cp++)
                {
-                  if (qz < qz0 || qz >= qz1) { continue; }
-#pragma unroll
-                  for (int cp = 0; cp < 3; cp++)
-                  {
-                     const double2 v = load_pa<NT>(&Db[(qz*3 + cp)*(NBZ*QQ)]);
-                     O[qz][(2*cp) % NC] = v.x; O[qz][(2*cp + 1) % NC] = v.y;
-                  }
+                  const double2 v = load_pa<NTP>(&Db[(qz*3 + cp)*(NBZ*QQ)]);
+                  O[qz][(2*cp) % NC] = v.x; O[qz][(2*cp + 1) % NC] = v.y;
                }
             }
-            else
-            {
-               const double *Db = Dq + (VEC ? comp*va.d_comp_stride : 0) + bt*(int64_t)(Q*NBZ*QQ) + tz*QQ + b*Q + a;
+         }
+         else
+         {
+            const double *Db = Dq + (VEC ? comp*va.d_comp_stride : 0) + bt*(int64_t)(Q*NBZ*QQ) + tz*QQ + b*Q + a;
 #pragma unroll
-               for (int qz = 0; qz < Q; qz++) { if (qz >= qz0 && qz < qz1) { O[qz][0] = load_pa<NT>(&Db[qz*(NBZ*QQ)]); } }
-            }
-         };
-         if (sched & SCHED_NT) { columns(std::true_type{}); } else { columns(std::false_type{}); }
+            for (int qz = 0; qz < Q; qz++) { if (qz >= qz0 && qz < qz1) { O[qz][0] = load_pa<NTP>(&Db[qz*(NBZ*QQ)]); } }
+         }
          return;
       }
       const int64_t ec = e < elast ? e : elast;
@@ -1048,7 +1044,7 @@ static int apply_rb(int KIND, int D, int Q)
    return rb_table(KIND, D, Q);
 }
 
-// SCHED_NT for a blocked pa_data of `bytes`: non-temporal once it cannot stay in the 256 MiB Infinity Cache beside
+// the non-temporal instantiation for a blocked pa_data of `bytes`: once it cannot stay in the 256 MiB Infinity Cache beside
 // the vectors and index tables of the application
 static int apply_nt(int64_t bytes)
 {
@@ -1058,8 +1054,8 @@ static int apply_nt(int64_t bytes)
       const char *v = getenv("MFEM_AMD_APPLY_NT");
       forced = (v && (*v == '0' || *v == '1')) ? (*v - '0') : -1;
    }
-   if (forced >= 0) { return forced ? SCHED_NT : 0; }
-   return bytes > ((int64_t)192 << 20) ? SCHED_NT : 0;
+   if (forced >= 0) { return forced; }
+   return bytes > ((int64_t)192 << 20) ? 1 : 0;
 }
 
 template <int KIND, int D, int Q, bool GATHER, bool ACCUM, bool BLK, int PF = 0, int RB = 0, bool RESOLVED = false>
@@ -1087,8 +1083,13 @@ static int launch_apply(int64_t ne, const double *B, const double *G, const doub
 #undef MFA_VARIANT
    }
    const int mode = apply_mode(KIND, D, Q);   // 0 one batch per workgroup, 1 persistent/contiguous, 2 persistent/round-robin
-   auto kern = k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM, BLK, 0, true, PF, RB>;
-   auto kern1 = k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM, BLK, 0, false, PF, RB>;
+   // non-temporal instantiations exist for the blocked-layout gather kernels that hold whole pa_data columns
+   constexpr bool NTV = BLK && GATHER && !ACCUM && PF == 0;
+   const bool nt = NTV && apply_nt((int64_t)sizeof(double)*blocked_size(KIND, Q, ne));
+   auto kern = nt ? k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM, BLK, 0, true, PF, RB, false, NTV>
+                  : k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM, BLK, 0, true, PF, RB>;
+   auto kern1 = nt ? k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM, BLK, 0, false, PF, RB, false, NTV>
+                   : k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM, BLK, 0, false, PF, RB>;
    // resident workgroups on the current device (queried once per instantiation and device)
    static int resident[64] = {0};
    int dev = 0;
@@ -1108,17 +1109,16 @@ static int launch_apply(int64_t ne, const double *B, const double *G, const doub
    fill_basis(bg, D, Q, B, G);
    const int64_t nb = (ne + NBZ - 1)/NBZ;
    if (nb == 0) { return 0; }
-   const int nt = BLK ? apply_nt((int64_t)sizeof(double)*blocked_size(KIND, Q, ne)) : 0;
    if (mode == 0)
    {
       MFA_REQUIRE(nb < (int64_t)2147483647, "pa_apply: too many workgroups (%lld)", (long long)nb);
       static const int xcd = (getenv("MFEM_AMD_APPLY_XCD") && atoi(getenv("MFEM_AMD_APPLY_XCD"))) ? 2 : 1;
-      kern1<<<dim3((unsigned)nb), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, xcd | nt, bg, Dq, x, gmap, yE, VecArgs{});
+      kern1<<<dim3((unsigned)nb), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, xcd, bg, Dq, x, gmap, yE, VecArgs{});
    }
    else
    {
       const unsigned grid = (unsigned)(nb < resident[dev] ? nb : resident[dev]);
-      kern<<<dim3(grid), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, (mode == 2 ? 1 : 0) | nt, bg, Dq, x, gmap, yE, VecArgs{});
+      kern<<<dim3(grid), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, mode == 2 ? 1 : 0, bg, Dq, x, gmap, yE, VecArgs{});
    }
    MFA_CHECK_LAUNCH("k_pa_apply");
    return 0;
@@ -1209,14 +1209,16 @@ static int launch_apply_vec(int64_t ne, const double *B, const double *G, const 
 {
    constexpr int NBZ = nbz_for(Q);
    constexpr int RBV = Q > 3 ? rb_table(KIND, D, Q) : 0;
-   auto kern = k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM, BLK, 0, false, 0, RBV, true>;
+   constexpr bool NTV = BLK && GATHER && !ACCUM;
+   const bool nt = NTV && apply_nt((int64_t)sizeof(double)*blocked_size(KIND, Q, ne)*(va.d_comp_stride ? va.vd : 1));
+   auto kern = nt ? k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM, BLK, 0, false, 0, RBV, true, NTV>
+                  : k_pa_apply<KIND, D, Q, NBZ, GATHER, ACCUM, BLK, 0, false, 0, RBV, true>;
    BasisTT<D*Q> bg;
    fill_basis(bg, D, Q, B, G);
    const int64_t nb = (ne + NBZ - 1)/NBZ;
    if (nb == 0) { return 0; }
    MFA_REQUIRE(nb < (int64_t)2147483647, "pa_apply: too many workgroups (%lld)", (long long)nb);
-   const int nt = BLK ? apply_nt((int64_t)sizeof(double)*blocked_size(KIND, Q, ne)*(va.d_comp_stride ? va.vd : 1)) : 0;
-   kern<<<dim3((unsigned)nb), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, 1 | nt, bg, Dq, x, gmap, yE, va);
+   kern<<<dim3((unsigned)nb), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, 1, bg, Dq, x, gmap, yE, va);
    MFA_CHECK_LAUNCH("k_pa_apply (vector)");
    return 0;
 }

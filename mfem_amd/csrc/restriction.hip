@@ -243,7 +243,7 @@ __device__ __forceinline__ void scatter_block_rows(const int64_t ndofs, const in
             double r = val[j];
             if (mk[j]) { r = (mk[j] == 1) ? xin[i] : 0.0; }
             if (MODE == 1) { r += y[i]; }
-            if (NT) { __builtin_nontemporal_store(r, &y[i]); } else { y[i] = r; }
+            y[i] = r;      // cached: the caller's next kernel reads it (a non-temporal store measured no different)
             if (DOT) { prod += wv[j]*r; }
          }
       }
