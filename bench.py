@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--p", type=int, default=4)
     ap.add_argument("--elems", type=int, default=0, help="elements per direction per GPU (default: ~1e7 dofs per GPU)")
     ap.add_argument("--problem", default="bp3", choices=["bp1", "bp2", "bp3", "bp4", "bp5", "bp6"])
-    ap.add_argument("--cg-iters", type=int, default=50)
+    ap.add_argument("--cg-iters", type=int, default=100)
     ap.add_argument("--no-orders", action="store_true", help="skip the p = 1..8 table (N=1 only; ~10 s)")
     ap.add_argument("--no-sizes", action="store_true", help="skip the BP1/BP3/BP5 x 1e5..1e8 dofs table (N=1 only; ~1 min)")
     ap.add_argument("--no-cpu", action="store_true")

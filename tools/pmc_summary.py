@@ -11,7 +11,7 @@ root = Path(sys.argv[1])
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in root.rglob("*counter_collection.csv"):
     for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"].split("(")[0][-60:]
+        k = row["Kernel_Name"].split("(")[0][-90:]
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = []
 avg = {}
@@ -37,7 +37,7 @@ if "--traffic-json" in sys.argv:
                         "FETCH_SIZE_KiB": d["FETCH_SIZE"], "WRITE_SIZE_KiB": d["WRITE_SIZE"],
                         "TCC_EA0_RDREQ": d.get("TCC_EA0_RDREQ_sum"), "TCC_EA0_WRREQ": d.get("TCC_EA0_WRREQ_sum")}
         return None
-    l2e = kernel_bytes(lambda k: "apply<" in k)
+    l2e = kernel_bytes(lambda k: "k_pa_apply<" in k or "apply<" in k)
     e2l = kernel_bytes(lambda k: "k_scatter<0, false>" in k)
     if not l2e:
         sys.exit("no k_pa_apply dispatches with FETCH_SIZE and WRITE_SIZE found")
