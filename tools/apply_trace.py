@@ -18,7 +18,7 @@ def report(path):
     for i in range(len(rows) - 2):
         a, s, n = rows[i], rows[i + 1], rows[i + 2]
         if "k_pa_apply" in a["Kernel_Name"] and "k_scatter" in s["Kernel_Name"] and "k_pa_apply" in n["Kernel_Name"]:
-            key = a["Kernel_Name"].split("(")[0][-44:]
+            key = a["Kernel_Name"].split("(")[0].split("k_pa_apply")[-1]
             d = out.setdefault(key, [[], [], [], []])
             d[0].append(int(a["End_Timestamp"]) - int(a["Start_Timestamp"]))
             d[1].append(int(s["Start_Timestamp"]) - int(a["End_Timestamp"]))
