@@ -209,3 +209,41 @@ def test_vector_bakeoff_known_answers(case):
     assert res.converged == 1
     k = min(res.iterations, case["pcg_its"])
     check_iterations("python", case["problem"], p, res.iterations, case["pcg_its"], hist[0], hist[k - 1])
+
+
+def test_cache_policy_instantiations_are_bit_identical():
+    """The non-temporal instantiations of the element kernel (picked above 192 MiB of pa_data) and the non-temporal
+    index loads of the E->L kernel (above 3e6 dofs) change the cache policy of loads, nothing else: y = A x and the
+    fused PCG of a 4.2e6-dof problem are the same bits with the policies forced off and on (MFEM_AMD_APPLY_NT,
+    MFEM_AMD_SCATTER_NT), for BP3 and BP1 and for a streamed-pa_data shape."""
+    import hashlib  # noqa: F401
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = (
+        "import hashlib, torch\n"
+        "from mfem_amd import capi\n"
+        "from mfem_amd.bp import BakeoffProblem\n"
+        "torch.cuda.init(); capi.call('mfem_amd_init', 0)\n"
+        "dev = torch.device('cuda', 0)\n"
+        "for prob, p, n in (('bp3', 2, 80), ('bp1', 4, 40), ('bp3', 7, 23), ('bp4', 2, 56)):\n"
+        "    bp = BakeoffProblem(prob, p, (n, n, n), dev)\n"
+        "    g = torch.Generator(device='cpu'); g.manual_seed(5)\n"
+        "    nv = bp.ndofs\n"
+        "    x = torch.rand(nv, dtype=torch.float64, generator=g).to(dev)\n"
+        "    y = torch.empty_like(x)\n"
+        "    bp.mult(x, y)\n"
+        "    rhs = torch.rand(nv, dtype=torch.float64, generator=g).to(dev); rhs[bp.ess.long()] = 0.0\n"
+        "    X, res, _ = bp.pcg(rhs, 0.0, max_iter=5, check_every=5)\n"
+        "    torch.cuda.synchronize()\n"
+        "    print(prob, p, bp.ndofs, hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest()[:16],\n"
+        "          hashlib.sha256(X.cpu().numpy().tobytes()).hexdigest()[:16], res.iterations)\n")
+    outs = []
+    for nt in ("0", "1"):
+        env = dict(os.environ, MFEM_AMD_APPLY_NT=nt, MFEM_AMD_SCATTER_NT=nt)
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("bp")])
+    assert len(outs[0]) == 4 and outs[0] == outs[1], (outs[0], outs[1])
