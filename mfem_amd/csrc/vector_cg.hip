@@ -537,8 +537,9 @@ static int pcg_impl(const mfem_amd_pa_operator *op, const mfem_amd_comm *comm, c
    MFA_CHECK_LAUNCH("k_pcg_den_scalars");
 
    // The reference's loop body runs at least once, even for max_iter == 0.
-   // (Finishing the two reductions inside the kernels that produce them, by the last workgroup to arrive, was
-   // measured and rejected: profiles/r2/pcg_fused_finish_probe.txt.)
+   // (Finishing the two reductions inside the kernels that produce them, by the last workgroup to arrive, and
+   // folding the scalar steps into the prologues of the kernels that consume them were both measured and
+   // rejected: profiles/r2/pcg_fused_finish_probe.txt.)
    const int total = max_iter > 0 ? max_iter : 1;
    PcgState cur;
    int launched = 0;
