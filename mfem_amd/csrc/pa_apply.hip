@@ -992,7 +992,9 @@ static int apply_mode(int KIND, int D, int Q)
    if (forced >= 0) { return forced; }
    // measured (profiles/r1/sweep_modes.txt): one batch per workgroup wins up to p = 7 (BP3);
    // the persistent round-robin schedule wins where registers allow one wave per SIMD only
-   return (KIND == 1 && (D >= 9 || (D == 8 && Q == 8) || (D == 6 && Q == 6))) ? 2 : 0;
+   // ((6,6) was persistent with streamed pa_data after round 1's isolated sweep; in the alternating apply the plain
+   // form is 2 % faster: profiles/r2/ctx_sweep_bp5.txt)
+   return (KIND == 1 && (D >= 9 || (D == 8 && Q == 8))) ? 2 : 0;
 }
 
 typedef int (*apply_fn)(int64_t ne, const double *B, const double *G, const double *Dq,
@@ -1016,7 +1018,6 @@ static int apply_pf(int KIND, int D, int Q)
    {
       if (D >= 9) { return Q == D ? 3 : 2; }
       if (D == 8) { return 2; }
-      if (D == 6 && Q == 6) { return 3; }
       if (D == 5 && Q == 8) { return 2; }        // eight whole z-slices do not fit three waves' registers (40-92 B of scratch)
    }
    return 0;

@@ -563,8 +563,52 @@ void BilinearFormIntegrator::SetupPA(const FiniteElementSpace &fes, int kind_, C
                                                  g.nodesE.Read(), C.Read(), const_c, pa_layout,
                                                  pa_layout ? pa_data.ReadWrite() : pa_data.Write(), nullptr, nullptr));
 }
+void BilinearFormIntegrator::SetupPAComponents(const FiniteElementSpace &fes, int kind_, VectorCoefficient &VQ, const IntegrationRule &ir)
+{
+   MFEM_VERIFY(vector_integrator, "mfem_amd: per-component coefficients belong to the Vector* integrators");
+   vdim = fes.GetVDim();
+   MFEM_VERIFY(VQ.GetVDim() == vdim, "VQ vdim vs. vdim error");
+   Mesh *mesh = fes.GetMesh();
+   const FiniteElement *fe = fes.GetTypicalFE();
+   kind = kind_; ne = fes.GetNE();
+   maps = &fe->GetDofToQuad(ir, DofToQuad::TENSOR);
+   dofs1D = maps->ndof; quad1D = maps->nqpt;
+   pa_data_mfem.Destroy();
+   NodesAtRule g; prepare_nodes(*mesh, ir, g);
+   Vector C; int const_c, cd = 1;
+   eval_coefficient(*mesh, ir, nullptr, C, const_c, &VQ, nullptr, &cd);      // (vdim, Q^3, NE), or vdim constants
+   symmetric = true;
+   pa_layout = mfem_amd_has_specialization(kind, dofs1D, quad1D) ? 1 : 0;
+   const int64_t blk = mfem_amd_pa_data_size(kind, pa_layout, quad1D, ne);
+   MFEM_VERIFY(blk*vdim < (int64_t)2147483647, "mfem_amd: per-component pa_data too large for one Vector");
+   pa_data.SetSize((int)(blk*vdim));
+   if (pa_layout) { pa_data.Write(); pa_data = 0.0; }     // padding of the last batch must be finite
+   const int64_t npts = const_c ? 1 : (int64_t)ir.GetNPoints()*ne;
+   Vector Cc((int)npts), one_comp;
+   if (!pa_layout) { one_comp.SetSize((int)blk); }
+   const real_t *c = C.HostRead();
+   const int64_t eblk = blk/ne;                            // doubles per element (MFEM layout)
+   for (int k = 0; k < vdim; k++)
+   {
+      real_t *cc = Cc.HostWrite();
+      for (int64_t q = 0; q < npts; q++) { cc[q] = c[(int64_t)cd*q + k]; }
+      // blocked layout: one array per component, blk doubles apart; MFEM layout: the reference's (Q^3, NC, vdim, NE)
+      // (bilininteg_vecdiffusion_pa.cpp:133-134), the components of an element next to each other
+      MFEM_AMD_CALL(mfem_amd_pa_setup_from_nodes_3d(kind, g.Dn, quad1D, 1, ne, g.Bn.data(), g.Gn.data(), ir.GetWeights().Read(),
+                                                    g.nodesE.Read(), Cc.Read(), const_c, pa_layout,
+                                                    pa_layout ? pa_data.ReadWrite() + blk*k : one_comp.Write(), nullptr, nullptr));
+      if (!pa_layout)
+      {
+         internal::CopyRowsOnDevice(pa_data.ReadWrite() + eblk*k, sizeof(real_t)*eblk*vdim, one_comp.Read(), sizeof(real_t)*eblk,
+                                    sizeof(real_t)*eblk, (size_t)ne);
+      }
+   }
+   pa_comp_stride = pa_layout ? blk : eblk;                // MFEM layout: any non-zero value selects the interleaved form
+}
 const Vector &BilinearFormIntegrator::MFEMLayoutData() const
 {
+   MFEM_VERIFY(pa_comp_stride == 0, "mfem_amd: the E-vector (dispatch-table) seam of a vector integrator with a VectorCoefficient "
+               "is not built; use BilinearForm::Mult / FormLinearSystem");
    if (pa_layout == 0) { return pa_data; }
    if (pa_data_mfem.Size() == 0)
    {
@@ -621,7 +665,8 @@ void MassIntegrator::AssembleDiagonalPA(Vector &diag)
 void VectorDiffusionIntegrator::AssemblePA(const FiniteElementSpace &fes)
 {
    const FiniteElement &el = *fes.GetTypicalFE();
-   SetupPA(fes, 1, Q, IntRule ? *IntRule : DiffusionIntegrator::GetRule(el, el));
+   const IntegrationRule &ir = IntRule ? *IntRule : DiffusionIntegrator::GetRule(el, el);
+   if (VQ) { SetupPAComponents(fes, 1, *VQ, ir); } else { SetupPA(fes, 1, Q, ir); }
 }
 void VectorDiffusionIntegrator::AddMultPA(const Vector &x, Vector &y) const
 {
@@ -636,7 +681,8 @@ void VectorMassIntegrator::AssemblePA(const FiniteElementSpace &fes)
    const FiniteElement &el = *fes.GetTypicalFE();
    fes.GetMesh()->EnsureNodes();
    const int nodes_order = fes.GetMesh()->GetNodalFESpace()->GetMaxElementOrder();
-   SetupPA(fes, 0, Q, IntRule ? *IntRule : MassIntegrator::GetRule(el, el, nodes_order));
+   const IntegrationRule &ir = IntRule ? *IntRule : MassIntegrator::GetRule(el, el, nodes_order);
+   if (VQ) { SetupPAComponents(fes, 0, *VQ, ir); } else { SetupPA(fes, 0, Q, ir); }
 }
 void VectorMassIntegrator::AddMultPA(const Vector &x, Vector &y) const
 {
@@ -689,7 +735,7 @@ void PABilinearFormExtension::Mult(const Vector &x, Vector &y) const
       MFEM_VERIFY(bfi && bfi->vector_integrator, "mfem_amd: a vector space takes exactly one Vector{Mass,Diffusion}Integrator");
       MFEM_AMD_CALL(mfem_amd_pa_apply_L2E_vdim(bfi->kind, bfi->pa_layout, bfi->dofs1D, bfi->quad1D, bfi->ne, vd,
                                                fes->GetOrdering() == Ordering::byVDIM ? 1 : 0, fes->GetNDofs(),
-                                               bfi->maps->B.HostRead(), bfi->maps->G.HostRead(), bfi->pa_data.Read(), 0,
+                                               bfi->maps->B.HostRead(), bfi->maps->G.HostRead(), bfi->pa_data.Read(), bfi->pa_comp_stride,
                                                elem_restrict->GatherMap().Read(), nullptr, x.Read(), localY.Write(), nullptr));
    }
    else if (const BilinearFormIntegrator *bfi = SingleIntegrator())
@@ -730,22 +776,50 @@ void PABilinearFormExtension::AssembleDiagonal(Vector &diag) const
       const BilinearFormIntegrator *bfi = SingleIntegrator();
       MFEM_VERIFY(bfi && bfi->vector_integrator, "mfem_amd: a vector space takes exactly one Vector{Mass,Diffusion}Integrator");
       const int ndofs = fes->GetNDofs(), nd = fes->GetTypicalFE()->GetDof();
+      const int byvdim = fes->GetOrdering() == Ordering::byVDIM ? 1 : 0;
       Vector dE((int64_t)bfi->ne*nd), dS(ndofs);
-      dE = 0.0;
-      if (bfi->kind)
+      auto scalar_diagonal = [&](const real_t *pad)
       {
-         MFEM_AMD_CALL(mfem_amd_pa_diffusion_diag_3d(bfi->dofs1D, bfi->quad1D, bfi->ne, 1, bfi->maps->B.HostRead(), bfi->maps->G.HostRead(),
-                                                     bfi->pa_data.Read(), bfi->pa_layout, dE.ReadWrite(), nullptr));
-      }
-      else
+         dE = 0.0;
+         if (bfi->kind)
+         {
+            MFEM_AMD_CALL(mfem_amd_pa_diffusion_diag_3d(bfi->dofs1D, bfi->quad1D, bfi->ne, 1, bfi->maps->B.HostRead(), bfi->maps->G.HostRead(),
+                                                        pad, bfi->pa_layout, dE.ReadWrite(), nullptr));
+         }
+         else
+         {
+            MFEM_AMD_CALL(mfem_amd_pa_mass_diag_3d(bfi->dofs1D, bfi->quad1D, bfi->ne, bfi->maps->B.HostRead(), pad,
+                                                   bfi->pa_layout, dE.ReadWrite(), nullptr));
+         }
+         MFEM_AMD_CALL(mfem_amd_restrict_scatter(ndofs, elem_restrict->Offsets().Read(), elem_restrict->Indices().Read(), dE.Read(),
+                                                 dS.Write(), 0, 1, nullptr));
+      };
+      if (bfi->pa_comp_stride == 0)
       {
-         MFEM_AMD_CALL(mfem_amd_pa_mass_diag_3d(bfi->dofs1D, bfi->quad1D, bfi->ne, bfi->maps->B.HostRead(), bfi->pa_data.Read(),
-                                                bfi->pa_layout, dE.ReadWrite(), nullptr));
+         scalar_diagonal(bfi->pa_data.Read());
+         MFEM_AMD_CALL(mfem_amd_vec_replicate_vdim(ndofs, vd, byvdim, nullptr, dS.Read(), diag.Write(), nullptr));
+         return;
       }
-      MFEM_AMD_CALL(mfem_amd_restrict_scatter(ndofs, elem_restrict->Offsets().Read(), elem_restrict->Indices().Read(), dE.Read(),
-                                              dS.Write(), 0, 1, nullptr));
-      MFEM_AMD_CALL(mfem_amd_vec_replicate_vdim(ndofs, vd, fes->GetOrdering() == Ordering::byVDIM ? 1 : 0, nullptr, dS.Read(),
-                                                diag.Write(), nullptr));
+      // a coefficient per component: component c carries the diagonal of its own scalar operator
+      Vector part(Height());
+      real_t unit[16];
+      MFEM_VERIFY(vd <= 16, "mfem_amd: at most 16 components");
+      for (int c = 0; c < vd; c++)
+      {
+         if (bfi->pa_layout) { scalar_diagonal(bfi->pa_data.Read() + bfi->pa_comp_stride*c); }
+         else
+         {
+            // MFEM layout: pull component c out of the interleaved (Q^3, NC, vdim, NE) array
+            const int64_t eblk = bfi->pa_comp_stride;
+            Vector comp((int)(eblk*bfi->ne));
+            internal::CopyRowsOnDevice(comp.Write(), sizeof(real_t)*eblk, bfi->pa_data.Read() + eblk*c, sizeof(real_t)*eblk*vd,
+                                       sizeof(real_t)*eblk, (size_t)bfi->ne);
+            scalar_diagonal(comp.Read());
+         }
+         for (int k = 0; k < 16; k++) { unit[k] = (k == c) ? 1.0 : 0.0; }
+         MFEM_AMD_CALL(mfem_amd_vec_replicate_vdim(ndofs, vd, byvdim, unit, dS.Read(), c == 0 ? diag.Write() : part.Write(), nullptr));
+         if (c > 0) { MFEM_AMD_CALL(mfem_amd_vec_axpby(Height(), 1.0, diag.Read(), 1.0, part.Read(), diag.ReadWrite(), nullptr)); }
+      }
       return;
    }
    localY = 0.0;
@@ -841,7 +915,7 @@ bool PABilinearFormExtension::FillOperator(mfem_amd_pa_operator &op) const
    if (fes->GetVDim() > 1)
    {
       if (!bfi->vector_integrator) { return false; }
-      op.vdim = fes->GetVDim(); op.byvdim = fes->GetOrdering() == Ordering::byVDIM ? 1 : 0; op.pa_comp_stride = 0;
+      op.vdim = fes->GetVDim(); op.byvdim = fes->GetOrdering() == Ordering::byVDIM ? 1 : 0; op.pa_comp_stride = bfi->pa_comp_stride;
    }
    op.B = bfi->maps->B.HostRead(); op.G = bfi->maps->G.HostRead();
    op.pa_data = bfi->pa_data.Read();

@@ -41,6 +41,9 @@ void CopyToHost(void *dst, const void *src, size_t bytes)
 { if (bytes) { HOST_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); } }
 void CopyOnDevice(void *dst, const void *src, size_t bytes)
 { if (bytes) { HOST_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, 0)); } }
+// rows of `width` bytes, `spitch` apart at the source, to rows `dpitch` apart at the destination (device to device)
+void CopyRowsOnDevice(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t rows)
+{ if (width && rows) { HOST_HIP_CHECK(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDeviceToDevice, 0)); } }
 void DeviceSync() { HOST_HIP_CHECK(hipStreamSynchronize(0)); }
 }
 

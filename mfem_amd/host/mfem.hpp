@@ -57,6 +57,7 @@ void DeviceFree(void *p);
 void CopyToDevice(void *dst, const void *src, size_t bytes);
 void CopyToHost(void *dst, const void *src, size_t bytes);
 void CopyOnDevice(void *dst, const void *src, size_t bytes);
+void CopyRowsOnDevice(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t rows);
 void DeviceSync();
 
 /// Host buffer + lazily created device mirror with validity flags: the semantics of
@@ -981,6 +982,10 @@ protected:
    explicit BilinearFormIntegrator(const IntegrationRule *ir = nullptr) : IntRule(ir) {}
    void SetupPA(const FiniteElementSpace &fes, int kind, Coefficient *Q, const IntegrationRule &ir,
                 VectorCoefficient *VQ = nullptr, MatrixCoefficient *MQ = nullptr);
+   /// vector integrators with a VectorCoefficient: one scalar pa_data per component (coeff_vdim = vdim,
+   /// fem/integ/bilininteg_vecdiffusion_pa.cpp:109-134, bilininteg_vecmass_pa.cpp:57-75), pa_comp_stride apart
+   void SetupPAComponents(const FiniteElementSpace &fes, int kind, VectorCoefficient &VQ, const IntegrationRule &ir);
+   int64_t pa_comp_stride = 0;
    friend class PABilinearFormExtension;
    friend class BilinearForm;
 public:
@@ -1032,10 +1037,12 @@ public:
 /// operator on every component of a vector H1 space (scalar coefficient; CEED BP4/BP6).
 class VectorDiffusionIntegrator : public BilinearFormIntegrator
 {
-   Coefficient *Q;
+   Coefficient *Q; VectorCoefficient *VQ = nullptr;
 public:
    VectorDiffusionIntegrator(const IntegrationRule *ir = nullptr) : BilinearFormIntegrator(ir), Q(nullptr) { vector_integrator = true; }
    VectorDiffusionIntegrator(Coefficient &q, const IntegrationRule *ir = nullptr) : BilinearFormIntegrator(ir), Q(&q) { vector_integrator = true; }
+   /// one diffusion coefficient per component (fem/integ/bilininteg_vecdiffusion_pa.cpp:62-67)
+   VectorDiffusionIntegrator(VectorCoefficient &vq, const IntegrationRule *ir = nullptr) : BilinearFormIntegrator(ir), Q(nullptr), VQ(&vq) { vector_integrator = true; }
    void AssemblePA(const FiniteElementSpace &fes) override;
    void AddMultPA(const Vector &x, Vector &y) const override;
    void AssembleDiagonalPA(Vector &diag) override;
@@ -1043,10 +1050,12 @@ public:
 /// fem/bilininteg.hpp VectorMassIntegrator; PA in fem/integ/bilininteg_vecmass_pa.cpp (CEED BP2).
 class VectorMassIntegrator : public BilinearFormIntegrator
 {
-   Coefficient *Q;
+   Coefficient *Q; VectorCoefficient *VQ = nullptr;
 public:
    VectorMassIntegrator(const IntegrationRule *ir = nullptr) : BilinearFormIntegrator(ir), Q(nullptr) { vector_integrator = true; }
    VectorMassIntegrator(Coefficient &q, const IntegrationRule *ir = nullptr) : BilinearFormIntegrator(ir), Q(&q) { vector_integrator = true; }
+   /// diagonal (per-component) coefficient (fem/bilininteg.hpp VectorMassIntegrator(VectorCoefficient&))
+   VectorMassIntegrator(VectorCoefficient &vq, const IntegrationRule *ir = nullptr) : BilinearFormIntegrator(ir), Q(nullptr), VQ(&vq) { vector_integrator = true; }
    void AssemblePA(const FiniteElementSpace &fes) override;
    void AddMultPA(const Vector &x, Vector &y) const override;
    void AssembleDiagonalPA(Vector &diag) override;

@@ -268,3 +268,14 @@ def test_ex1p_cxx_ranks_match_serial_ex1(mesh, order):
     big = hs > 1e-10*hs[0]
     assert np.all(np.abs(h1[:k][big] - hs[big]) <= 1e-3*hs[big])
     assert np.all(np.abs(h1[:6] - hs[:6]) <= 2e-6*hs[:6])
+
+
+@pytest.mark.parametrize("flags", [["-p", "2", "-n", "3"], ["-p", "3", "-n", "2", "-fn"], ["-p", "4", "-n", "2", "-fn"]])
+def test_cxx_vector_integrators_with_vector_coefficient(flags):
+    """Vector{Mass,Diffusion}Integrator(VectorCoefficient&): component c of the operator, of its diagonal and of the
+    Jacobi-PCG solution equals the scalar integrator with coefficient c_k (coeff_vdim = vdim,
+    fem/integ/bilininteg_vecdiffusion_pa.cpp:109-134) -- operator and diagonal bit for bit, both orderings, on a
+    curved mesh; examples/vcoef_check.cpp.  No reference fixture exists for this case: pinned to the scalar path."""
+    out = subprocess.run([str(BIN / "vcoef_check")] + flags, capture_output=True, text=True, timeout=300, cwd=str(ROOT))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.strip().endswith("OK") and out.stdout.count("|y - y_scalar| = 0.000e+00") == 4
