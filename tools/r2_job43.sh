@@ -1,0 +1,9 @@
+#!/bin/bash
+mkdir -p gpurun_out
+for v in 0 1 0 1; do
+  MFEM_AMD_SCATTER_REV=$v timeout -k 10 300 python3 bench.py --no-cpu --no-sizes --cg-iters 0 > gpurun_out/bench_rev.log 2>&1 || { tail -3 gpurun_out/bench_rev.log; exit 1; }
+  grep -a "^{" gpurun_out/bench_rev.log | tail -1 | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.readline())
+print('REV=$v', 'p4 %.1f us' % (d['ms_per_step']*1e3), ' by_order us:', ' '.join('%.1f' % (r['ms_per_step']*1e3) for r in d['by_order']))"
+done
