@@ -136,7 +136,7 @@ __device__ __forceinline__ void scatter_block_rows(const int64_t ndofs, const in
                                                    const int *__restrict__ indices, const double *__restrict__ xE,
                                                    double *__restrict__ y, const unsigned char *__restrict__ marker,
                                                    const double *__restrict__ xin, const double *__restrict__ w,
-                                                   double &prod, double *__restrict__ sval)
+                                                   double &prod, double *__restrict__ sval, const int64_t bid)
 {
    constexpr int CAP = SCAT_CAP, K = CAP/256;
    const int t = threadIdx.x;
@@ -170,7 +170,7 @@ __device__ __forceinline__ void scatter_block_rows(const int64_t ndofs, const in
          if (256*k < cnt && e < cnt) { sval[e] = (id[k] >= 0 || MODE == 2) ? v[k] : -v[k]; }
       }
    };
-   for (int64_t base = (int64_t)blockIdx.x*1024; base < ndofs; base += (int64_t)gridDim.x*1024)
+   for (int64_t base = bid*1024; base < ndofs; base += (int64_t)gridDim.x*1024)
    {
       const int64_t last = ndofs - 1;
       int o0[4], n[4];
@@ -266,14 +266,18 @@ k_scatter(const int64_t ndofs, const int *__restrict__ offsets,
    // profiles/r2/e2l_blk_probe.txt): the block-cooperative form below 6 entries per row (p >= 2); long rows
    // (p = 1: 8 entries) overflow its LDS tile and are faster row per thread, 8 entries of two rows in flight.
    const int64_t nnz = offsets[ndofs];
-   // flags & 1: logical block id = XCD-contiguous (tuning aid); the partial sums stay indexed by the logical id
-   const int64_t bid = (flags & 1) ? xcd_remap(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
-   if (!(flags & 2) && nnz < 6*ndofs && !(flags & 1))
+   // Logical block id XCD-contiguous (the partial sums stay indexed by the logical id: same bits): where rows are
+   // long but still go through the block form (p = 2: 3.4 entries per row) the row blocks of one XCD then share their
+   // E-vector lines in that XCD's L2 -- 2.7 % on the whole apply at p = 2, neutral or slightly worse elsewhere
+   // (profiles/r2/xcd_probe.txt).  flags & 1 forces it everywhere (tuning aid).
+   const bool xcd = (flags & 1) || (!(flags & 2) && nnz >= 3*ndofs && nnz < 6*ndofs);
+   const int64_t bid = xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
+   if (!(flags & 2) && nnz < 6*ndofs)
    {
       // streamed-once operands non-temporal when the tables cannot stay in the Infinity Cache between applications
       // anyway (profiles/r2/e2l_nt_probe.txt); small problems keep everything cached
-      if ((flags & 4) && ndofs > 3000000) { scatter_block_rows<MODE, DOT, true>(ndofs, offsets, indices, xE, y, marker, xin, w, prod, sval); }
-      else { scatter_block_rows<MODE, DOT>(ndofs, offsets, indices, xE, y, marker, xin, w, prod, sval); }
+      if ((flags & 4) && ndofs > 3000000) { scatter_block_rows<MODE, DOT, true>(ndofs, offsets, indices, xE, y, marker, xin, w, prod, sval, bid); }
+      else { scatter_block_rows<MODE, DOT>(ndofs, offsets, indices, xE, y, marker, xin, w, prod, sval, bid); }
    }
    else if (nnz >= 3*ndofs) { scatter_rows<MODE, DOT, 8, 2>(ndofs, offsets, indices, xE, y, marker, xin, w, prod, bid); }
    else if (20*nnz >= 31*ndofs) { scatter_rows<MODE, DOT, 4, 4>(ndofs, offsets, indices, xE, y, marker, xin, w, prod, bid); }

@@ -1,9 +1,9 @@
 #!/bin/bash
 mkdir -p gpurun_out
 for v in 0 1 0 1; do
-  MFEM_AMD_APPLY_XCD=$v MFEM_AMD_SCATTER_XCD=0 timeout -k 10 300 python3 bench.py --no-cpu --no-sizes --cg-iters 0 > gpurun_out/bench_xcd.log 2>&1 || { tail -3 gpurun_out/bench_xcd.log; exit 1; }
+  MFEM_AMD_SCATTER_XCD=$v timeout -k 10 300 python3 bench.py --no-cpu --no-sizes --cg-iters 0 > gpurun_out/bench_xcd.log 2>&1 || { tail -3 gpurun_out/bench_xcd.log; exit 1; }
   grep -a "^{" gpurun_out/bench_xcd.log | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.readline())
-print('APPLY_XCD=$v', 'p4 %.1f us' % (d['ms_per_step']*1e3), ' by_order us:', ' '.join('%.1f' % (r['ms_per_step']*1e3) for r in d['by_order']))"
+print('SCATTER_XCD=$v', 'p4 %.1f us' % (d['ms_per_step']*1e3), ' by_order us:', ' '.join('%.1f' % (r['ms_per_step']*1e3) for r in d['by_order']))"
 done
