@@ -141,6 +141,25 @@ def main():
         el = float(tt.item())
     value = total_dofs*args.steps/el/1e9
 
+    # the same K steps replayed from one HIP graph (N = 1; reported beside the eager figure, never as `value`: the
+    # N > 1 lines are eager and the driver compares them with this one)
+    replay = None
+    if world == 1:
+        side = torch.cuda.Stream(dev)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            bp.use_stream(side)
+            gr.capture_begin()
+            for _ in range(args.steps):
+                step()
+            gr.capture_end()
+        bp.use_stream(torch.cuda.current_stream(dev))
+        gr.replay(); torch.cuda.synchronize()
+        quiesce()
+        tr = sorted(timed(gr.replay, 1) for _ in range(3))[1]/args.steps
+        replay = {"launch": f"hip graph of {args.steps} applies", "ms_per_step": tr*1e3, "GDOF/s": total_dofs/tr/1e9}
+        del gr
+
     # per-kernel average launch durations on this rank (HIP events on the launch stream), K launches per
     # block; the median of three blocks (box-to-box and clock noise is +-5 % on a 17 ms block)
     quiesce()
@@ -170,7 +189,7 @@ def main():
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
-        _, res, _ = bp.pcg(rhs, 0.0, max_iter=args.cg_iters, check_every=args.cg_iters)
+        _, res, _ = bp.pcg(rhs, 0.0, max_iter=args.cg_iters, check_every=cg_check(args.cg_iters))
         torch.cuda.synchronize()
         tcg = time.perf_counter() - t0
         if world > 1:
@@ -212,12 +231,18 @@ def main():
                                       f"D1D={D} Q1D={Q}, Cartesian hex mesh {n}^3 per GPU",
                           "elements_per_gpu": ne, "local_dofs_per_gpu": ndofs, "global_dofs": total_dofs,
                           "process_grid": list(pg), "transport": transport},
-               "roofline": roof, "roofline_apply": roof_apply, "cg": cg, "by_order": by_order, "by_size": by_size,
+               "roofline": roof, "roofline_apply": roof_apply, "graph_replay": replay, "cg": cg, "by_order": by_order, "by_size": by_size,
                "cpu_baseline": cpu,
                "setup_s": setup_s}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def cg_check(iters):
+    """Iterations per host poll of the timed solves (MFEM_AMD_BENCH_CG_CHECK overrides)."""
+    e = os.environ.get("MFEM_AMD_BENCH_CG_CHECK")
+    return max(1, int(e)) if e else iters
 
 
 def quiesce():
@@ -291,7 +316,7 @@ def size_row(problem, p, dofs, dev, gen, cg_iters=20):
     xq = torch.rand(bq.ndofs, dtype=torch.float64, generator=gen).to(dev)
     yq = torch.empty_like(xq)
     b1, b2 = algorithmic_bytes(bq.kind, bq.D, bq.Q, bq.ne, bq.ndofs)
-    graph = bq.ndofs < 3_000_000
+    graph = bq.ndofs < 3_000_000 or os.environ.get("MFEM_AMD_BENCH_GRAPH") == "1"      # (forced: the 1e7-dof comparison of DESIGN 5)
     # enough applies per timed block for >= ~4 ms of device work
     k = int(min(400, max(20, 4.0e-3/max(2.0e-6, (b1 + b2)/5.0e12))))
 
@@ -331,7 +356,7 @@ def size_row(problem, p, dofs, dev, gen, cg_iters=20):
         bq.pcg(rhs, 0.0, max_iter=3, check_every=3)
         quiesce()
         t0 = time.perf_counter()
-        _, res, _ = bq.pcg(rhs, 0.0, max_iter=cg_iters, check_every=cg_iters)
+        _, res, _ = bq.pcg(rhs, 0.0, max_iter=cg_iters, check_every=cg_check(cg_iters))
         torch.cuda.synchronize()
         tcg = time.perf_counter() - t0
         row["cg_dofs_iter_per_s"] = bq.ndofs*res.iterations/tcg
