@@ -308,7 +308,37 @@ typedef struct mfem_amd_pa_operator
    int vdim, byvdim;
    int64_t pa_comp_stride;   /* 0: one pa_data shared by all components (scalar coefficient);
                                 else doubles between the components' pa_data arrays */
+   int64_t direct_rows;      /* 0, or what mfem_amd_interior_rows returned for gather_map / offsets: the last direct_rows
+                                L-rows are element-interior dofs, which the element kernel writes itself (scalar spaces) */
 } mfem_amd_pa_operator;
+
+/* Element-interior dofs belong to one element, so their rows of G^T are single entries: when they are the LAST
+ * NE*(D1D-2)^3 L-dofs, numbered element by element in lexicographic order -- as the reference numbers every H1 space
+ * (vertex, edge, face, then interior dofs: fem/fespace.cpp, FiniteElementSpace::BuildDofToArrays and the H1 dof maps of
+ * fem/fe/fe_h1.cpp) -- the element kernel can store them straight into y and ElementRestriction::MultTranspose
+ * (fem/restriction.cpp:152-180) only has to sum the rows before them: 22 % (p = 4) to 47 % (p = 8) of the E-vector
+ * never goes through memory.  Same values, bit for bit.  This checks the property on the device (every interior entry
+ * of gather_map and the row lengths in offsets) and returns NE*(D1D-2)^3 in *direct_rows (HOST) or 0.
+ * work: one int of device memory.  Synchronises the stream. */
+int mfem_amd_interior_rows(int D1D, int64_t ne, int64_t ndofs, const int *gather_map, const int *offsets,
+                           int *work, int64_t *direct_rows, void *stream);
+
+/* The element kernel of mfem_amd_pa_apply_L2L alone (mfem_amd_pa_apply_L2E with the element-interior rows stored to
+ * y_interior[e*(D1D-2)^3 + lexicographic interior index] instead of to yE; the other entries of yE as always).
+ * y_interior = y + ndofs - direct_rows for a space that passed mfem_amd_interior_rows.  For callers that run the
+ * two halves of the apply themselves (timing, overlap with an exchange). */
+int mfem_amd_pa_apply_L2E_direct(int kind, int pa_layout, int D1D, int Q1D, int64_t ne,
+                                 const double *B, const double *G, const double *D,
+                                 const int *gather_map, const double *x, double *yE,
+                                 double *y_interior, void *stream);
+
+/* PABilinearFormExtension::Mult on L-vectors (fem/bilinearform_ext.cpp:487-564: ElementRestriction::Mult, the
+ * integrator's AddMultPA, ElementRestriction::MultTranspose) as two kernels: y = G^T A_E G x.
+ * direct_rows: 0 or the value from mfem_amd_interior_rows.  yE: NE*D1D^3 doubles of work space. */
+int mfem_amd_pa_apply_L2L(int kind, int pa_layout, int D1D, int Q1D, int64_t ne, int64_t ndofs,
+                          const double *B, const double *G, const double *D, const int *gather_map,
+                          const int *offsets, const int *indices, int64_t direct_rows,
+                          const double *x, double *yE, double *y, void *stream);
 
 /* ConstrainedOperator(PABilinearFormExtension)::Mult, DIAG_ONE
  * (linalg/operator.cpp:586-646 over fem/bilinearform_ext.cpp:487-564):

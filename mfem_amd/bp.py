@@ -21,7 +21,8 @@ def _p(t):
 
 
 class BakeoffProblem:
-    def __init__(self, problem, p, n, device, part=None, exchange=None, layout=1, device_tables=False):
+    def __init__(self, problem, p, n, device, part=None, exchange=None, layout=1, device_tables=False,
+                 numbering="lexicographic"):
         """`part`: None (serial Cartesian box of n elements), a BoxPartition, or a GeneralPartition of any hex
         mesh's tables (then n is ignored).  device_tables: build the E->L table (`offsets`, `indices`) from the
         gather map on the device (a stable sort by L-dof = the reference's (element, local index) order within a
@@ -71,6 +72,23 @@ class BakeoffProblem:
                 self.e_split = 0
         self._nodes_E = nodes_E
         self.gm = t(gather_map)
+        # numbering = "interior-last": vertex/edge/face dofs first (in their lexicographic order), then the element-
+        # interior dofs element by element -- the class of numberings the reference gives every H1 space
+        # (fem/fespace.cpp) -- so that mfem_amd_interior_rows applies.  self.perm[old] = new.
+        self.perm = None
+        if numbering == "interior-last" and part is None and D >= 3 and not self.vdim:
+            ni = (D - 2)**3
+            inter = self.gm.view(self.ne, D, D, D)[:, 1:-1, 1:-1, 1:-1].reshape(-1).long()
+            is_int = torch.zeros(pr.ndofs, dtype=torch.bool, device=self.dev)
+            is_int[inter] = True
+            i0 = pr.ndofs - self.ne*ni
+            perm = torch.empty(pr.ndofs, dtype=torch.int64, device=self.dev)
+            perm[~is_int] = torch.arange(i0, device=self.dev)
+            perm[inter] = i0 + torch.arange(self.ne*ni, device=self.dev)
+            self.gm = perm[self.gm.long()].to(torch.int32)
+            self.perm = perm
+            offsets = None
+            del inter, is_int
         if offsets is None:
             ind = torch.sort(self.gm, stable=True).indices
             self.ind = ind.to(torch.int32)
@@ -89,6 +107,8 @@ class BakeoffProblem:
             marker, ess = part.essential_marker()
         else:
             ess = pr.boundary_dofs()
+            if self.perm is not None:
+                ess = self.perm[torch.from_numpy(np.asarray(ess, np.int64)).to(self.dev)].cpu().numpy()
             marker = np.zeros(self.nscalar, np.uint8); marker[ess] = 1
         if self.vdim:
             ess = (ess.astype(np.int64)[:, None]*vd + np.arange(vd)[None, :]).reshape(-1)      # byVDIM vdofs
@@ -103,6 +123,14 @@ class BakeoffProblem:
         self.op = capi.PaOperator(kind, layout, D, Q, self.ne, self.nscalar, vp(self.B), vp(self.G), _p(self.pa),
                                   _p(self.gm), _p(self.masked), _p(self.off), _p(self.ind), len(ess), _p(self.ess),
                                   _p(self.marker), _p(self.yE), self.vdim, 1 if self.vdim else 0, 0)
+        # element-interior rows the element kernel may write itself (include/mfem_amd.h: mfem_amd_interior_rows)
+        self.direct = 0
+        if not self.vdim and part is None and os.environ.get("MFEM_AMD_DIRECT_ROWS", "1") != "0":
+            work = torch.zeros(1, dtype=torch.int32, device=self.dev)
+            dr = C.c_int64(0)
+            capi.call("mfem_amd_interior_rows", D, self.ne, self.nscalar, _p(self.gm), _p(self.off), _p(work), C.byref(dr), self.stream)
+            self.direct = int(dr.value)
+        self.op.direct_rows = self.direct
         self.ghost = None
         if part is not None:
             g = np.asarray(part.ext_ldof, np.int64)
@@ -118,10 +146,21 @@ class BakeoffProblem:
         self.stream = C.c_void_p(stream.cuda_stream)
 
     # ---- BilinearForm::Mult (unconstrained L->L), the BK "Kernel" of bench_ceed.cpp:163-190
-    def l2e(self, x, e0=0, e1=None):
-        """element kernel over the elements [e0, e1) (e0 on a batch boundary of the blocked layout)"""
+    def direct_active(self):
+        """does mult() write the element-interior rows from the element kernel? (vector_cg.hip: constrained_mult)"""
+        pol = int(os.environ.get("MFEM_AMD_DIRECT", "1"))
+        return bool(self.direct) and (pol == 2 or (pol == 1 and self.nscalar*8 <= (256 << 20)))
+
+    def l2e(self, x, e0=0, e1=None, y=None):
+        """element kernel over the elements [e0, e1) (e0 on a batch boundary of the blocked layout); with y, and where
+        mult() does so, the element-interior rows go to y as in mult()"""
         e1 = self.ne if e1 is None else e1
         if e1 <= e0:
+            return
+        if y is not None and self.direct_active() and e0 == 0 and e1 == self.ne:
+            yi = C.c_void_p(y.data_ptr() + 8*(self.nscalar - self.direct))
+            capi.call("mfem_amd_pa_apply_L2E_direct", self.kind, self.layout, self.D, self.Q, self.ne, self.B, self.G, _p(self.pa),
+                      _p(self.gm), _p(x), _p(self.yE), yi, self.stream)
             return
         D3, vd = self.D**3, max(1, self.vdim)
         nc = 6 if self.kind else 1
@@ -141,7 +180,8 @@ class BakeoffProblem:
             capi.call("mfem_amd_restrict_scatter_vdim", self.nscalar, self.D**3, self.vdim, 1, _p(self.off), _p(self.ind),
                       _p(self.yE), _p(y), 0, 0, self.stream)
             return
-        capi.call("mfem_amd_restrict_scatter", self.ndofs, _p(self.off), _p(self.ind), _p(self.yE), _p(y), 0, 0, self.stream)
+        rows = self.ndofs - self.direct if self.direct_active() else self.ndofs        # as mult() does
+        capi.call("mfem_amd_restrict_scatter", rows, _p(self.off), _p(self.ind), _p(self.yE), _p(y), 0, 0, self.stream)
 
     def mult(self, x, y):
         """y = A x; in parallel x's ghost entries are refreshed first and y ends with owners
@@ -160,6 +200,10 @@ class BakeoffProblem:
             self.l2e(x, self.e_split, self.ne)
             self.e2l(y)
             self.ex.reverse(y.data_ptr(), self.stream)
+            return
+        if self.ex is None and not self.vdim:
+            capi.call("mfem_amd_pa_apply_L2L", self.kind, self.layout, self.D, self.Q, self.ne, self.nscalar, self.B, self.G,
+                      _p(self.pa), _p(self.gm), _p(self.off), _p(self.ind), self.direct, _p(x), _p(self.yE), _p(y), self.stream)
             return
         if self.ex is not None:
             self.ex.forward(x.data_ptr(), self.stream)

@@ -144,6 +144,9 @@ struct VecArgs
                                   // the components' arrays; MFEM layout: nonzero = (Q^3,NC,vd,NE) as the reference
    int64_t d_block;               // MFEM layout: doubles per (element, component) block; 0 = NC*Q^3.  The reference's
                                   // vector diffusion allocates dim*dim = 9 planes per block and fills 6
+   double *ydirect;               // scalar gather kernels, optional: the L-vector rows of the element-interior dofs, element e's
+                                  // (D-2)^3 rows at ydirect + e*(D-2)^3 in lexicographic order -- written here instead of
+                                  // to the E-vector (mfem_amd_interior_rows)
 };
 
 // Workgroup sum for blockDim.x == 256 (4 waves); result valid in thread 0.

@@ -142,6 +142,8 @@ __device__ __forceinline__ void phase_sync()
 // indices -- and, when all components share one pa_data (scalar coefficient), the pa_data
 // columns -- held in registers: pa_data is read once for vd components, where the reference
 // stores and reads vd identical copies.  E-vectors are (D,D,D,vd,NE) as in the reference.
+typedef __attribute__((address_space(1))) double gdouble;   // global memory, for addresses built from integers
+
 template <int KIND, int D, int Q, int NBZ, bool GATHER, bool ACCUM, bool BLK = false, int ABL = 0, bool PERSIST = true, int PF = 0, int RB = 0, bool VEC = false, bool NTP = false>
 __global__ void __launch_bounds__(Q*Q*NBZ, minw_for(KIND, D, PF, RB, VEC, Q)) MFA_VGPR_CAP
 k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const BasisTT<D*Q> bg,
@@ -152,6 +154,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
    constexpr int NC = KIND ? 6 : 1;       // stored components per quadrature point
    constexpr int NF = KIND ? 3 : 1;       // fields carried through the z loop
    constexpr int NX = KIND ? 2 : 1;       // fields after the x contraction (B x, G x)
+   constexpr bool DIRECT = GATHER && !ACCUM && !VEC && ABL == 0 && D >= 3;   // va.ydirect honoured
    // LDS strides (doubles): rows that one thread walks (sX, sBX/sGX, sV) are padded to an odd
    // length; the (qy,qx) planes of sT keep dense rows and get a small pad as a whole for even Q.
    // (Measured: padding or transposing the planes so that the row-per-thread reads are entirely
@@ -730,7 +733,26 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
                   yv[dx] = y;
                }
                double *ye = yE + (VEC ? e*va.vd + comp : e)*D3 + t2*D;
-               if (D % 2 == 0)
+               // rows of element-interior dofs belong to this element alone: their sums ARE these values, so they
+               // go straight to the L-vector and never through the E-vector (uniform branch on a kernel argument)
+               if (DIRECT && va.ydirect)
+               {
+                  // One store per value, its address chosen per lane by mask arithmetic: the rows of one wave differ in
+                  // kind, and a branch would issue both forms of the row one after the other.  (Not `c ? p : q` on the
+                  // pointers: hipcc 7.2 turns that back into exec-masked blocks and sinks one of the moves out of its
+                  // block -- lanes of dy = 0 then stored through their neighbour row's address.)
+                  constexpr int DI = D - 2;
+                  const bool inner = t2 >= D && t2 < D*(D - 1) && t2 % D >= 1 && t2 % D <= D - 2;
+                  const uint64_t pe = reinterpret_cast<uint64_t>(ye);
+                  const uint64_t pd = reinterpret_cast<uint64_t>(va.ydirect + e*(DI*DI*DI) + ((t2/D - 1)*DI + (t2 % D - 1))*DI - 1);
+                  const uint64_t pin = pe ^ ((pe ^ pd) & (uint64_t)(-(int64_t)inner));
+#pragma unroll
+                  for (int dx = 0; dx < D; dx++)
+                  {
+                     *reinterpret_cast<gdouble*>(((dx >= 1 && dx <= DI) ? pin : pe) + 8u*dx) = yv[dx];
+                  }
+               }
+               else if (D % 2 == 0)
                {
                   double2 *ye2 = reinterpret_cast<double2*>(ye);      // e*D3 + t2*D is even: 16-B aligned
 #pragma unroll
@@ -769,7 +791,15 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
                   y += Bc[qx]*sV[(dz*D + b)*QP + qx];
                   if (KIND) { y += Gc[qx]*sV[DDQ + (dz*D + b)*QP + qx]; }
                }
-               if (ACCUM) { ye[dz*D*D] += y; }
+               if (DIRECT && va.ydirect)
+               {
+                  constexpr int DI = D - 2;
+                  const bool inner = a >= 1 && a <= DI && b >= 1 && b <= DI && dz >= 1 && dz <= DI;
+                  const uint64_t pe = reinterpret_cast<uint64_t>(ye + dz*D*D);
+                  const uint64_t pd = reinterpret_cast<uint64_t>(va.ydirect + e*(DI*DI*DI) + ((dz - 1)*DI + (b - 1))*DI + (a - 1));
+                  *reinterpret_cast<gdouble*>(pe ^ ((pe ^ pd) & (uint64_t)(-(int64_t)inner))) = y;     // (mask, not ?: -- see the RB form)
+               }
+               else if (ACCUM) { ye[dz*D*D] += y; }
                else { ye[dz*D*D] = y; }
             }
          }
@@ -944,7 +974,12 @@ k_pa_apply_generic(const int D, const int Q, const int64_t ne, const BasisT<MAX_
          y += sB[qx*D + dx]*s1[dyz*Q + qx];
          if (KIND) { y += sG[qx*D + dx]*s1[DDQ + dyz*Q + qx]; }
       }
-      if (ACCUM) { yE[eblk*D3 + i] += y; }
+      const int dy = dyz % D, dz = dyz/D, DI = D - 2;
+      if (GATHER && !ACCUM && va.ydirect && dx >= 1 && dx <= DI && dy >= 1 && dy <= DI && dz >= 1 && dz <= DI)
+      {
+         va.ydirect[(int64_t)blockIdx.x*(DI*DI*DI) + ((dz - 1)*DI + (dy - 1))*DI + (dx - 1)] = y;
+      }
+      else if (ACCUM) { yE[eblk*D3 + i] += y; }
       else { yE[eblk*D3 + i] = y; }
    }
 }
@@ -998,7 +1033,7 @@ static int apply_mode(int KIND, int D, int Q)
 }
 
 typedef int (*apply_fn)(int64_t ne, const double *B, const double *G, const double *Dq,
-                        const double *x, const int *gmap, double *yE, hipStream_t s);
+                        const double *x, const int *gmap, double *yE, double *ydir, hipStream_t s);
 
 // pa_data prefetch distance in z-slices (0 = hold all Q slices in registers); MFEM_AMD_APPLY_PF
 // overrides it (tuning aid; only the values compiled in are accepted).
@@ -1061,7 +1096,7 @@ static int apply_nt(int64_t bytes)
 
 template <int KIND, int D, int Q, bool GATHER, bool ACCUM, bool BLK, int PF = 0, int RB = 0, bool RESOLVED = false>
 static int launch_apply(int64_t ne, const double *B, const double *G, const double *Dq,
-                        const double *x, const int *gmap, double *yE, hipStream_t s)
+                        const double *x, const int *gmap, double *yE, double *ydir, hipStream_t s)
 {
    constexpr int NBZ = nbz_for(Q);
    constexpr bool HOT = BLK && GATHER && !ACCUM && Q > 3;
@@ -1077,7 +1112,7 @@ static int launch_apply(int64_t ne, const double *B, const double *G, const doub
       { \
          constexpr bool built = (P == 0) || (R == rb_table(KIND, D, Q)); \
          MFA_REQUIRE(built, "pa_apply: the variant PF=%d RB=%d of (%d,%d) is not compiled in", P, R, D, Q); \
-         return launch_apply<KIND, D, Q, GATHER, ACCUM, BLK, (HOT && built) ? P : 0, (HOT && built) ? R : 0, true>(ne, B, G, Dq, x, gmap, yE, s); \
+         return launch_apply<KIND, D, Q, GATHER, ACCUM, BLK, (HOT && built) ? P : 0, (HOT && built) ? R : 0, true>(ne, B, G, Dq, x, gmap, yE, ydir, s); \
       }
       MFA_VARIANT(0, 1) MFA_VARIANT(2, 0) MFA_VARIANT(2, 1) MFA_VARIANT(3, 0) MFA_VARIANT(3, 1)
       MFA_VARIANT(0, 2) MFA_VARIANT(2, 2) MFA_VARIANT(3, 2)
@@ -1110,16 +1145,19 @@ static int launch_apply(int64_t ne, const double *B, const double *G, const doub
    fill_basis(bg, D, Q, B, G);
    const int64_t nb = (ne + NBZ - 1)/NBZ;
    if (nb == 0) { return 0; }
+   MFA_REQUIRE(!ydir || (GATHER && !ACCUM && D >= 3), "pa_apply: interior rows can only be written by the gather kernels, D1D >= 3");
+   VecArgs va{};
+   va.ydirect = ydir;
    if (mode == 0)
    {
       MFA_REQUIRE(nb < (int64_t)2147483647, "pa_apply: too many workgroups (%lld)", (long long)nb);
       static const int xcd = (getenv("MFEM_AMD_APPLY_XCD") && atoi(getenv("MFEM_AMD_APPLY_XCD"))) ? 2 : 1;
-      kern1<<<dim3((unsigned)nb), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, xcd, bg, Dq, x, gmap, yE, VecArgs{});
+      kern1<<<dim3((unsigned)nb), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, xcd, bg, Dq, x, gmap, yE, va);
    }
    else
    {
       const unsigned grid = (unsigned)(nb < resident[dev] ? nb : resident[dev]);
-      kern<<<dim3(grid), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, mode == 2 ? 1 : 0, bg, Dq, x, gmap, yE, VecArgs{});
+      kern<<<dim3(grid), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, mode == 2 ? 1 : 0, bg, Dq, x, gmap, yE, va);
    }
    MFA_CHECK_LAUNCH("k_pa_apply");
    return 0;
@@ -1144,13 +1182,13 @@ static apply_fn find_apply(int D, int Q)
 template <int KIND, bool GATHER, bool ACCUM, bool BLK>
 static int run_apply(int D, int Q, int64_t ne, const double *B, const double *G,
                      const double *Dq, const double *x, const int *gmap, double *yE,
-                     hipStream_t s)
+                     hipStream_t s, double *ydir = nullptr)
 {
    MFA_REQUIRE(D >= 2 && D <= MAX_D1D && Q >= 1 && Q <= MAX_Q1D && D*Q <= MAX_DQ,
                "pa_apply: unsupported (D1D,Q1D) = (%d,%d); limits D1D<=%d, Q1D<=%d, D1D*Q1D<=%d",
                D, Q, MAX_D1D, MAX_Q1D, MAX_DQ);
    MFA_REQUIRE(B && Dq && x && yE && (KIND == 0 || G) && (!GATHER || gmap), "pa_apply: null pointer argument");
-   if (apply_fn f = find_apply<KIND, GATHER, ACCUM, BLK>(D, Q)) { return f(ne, B, G, Dq, x, gmap, yE, s); }
+   if (apply_fn f = find_apply<KIND, GATHER, ACCUM, BLK>(D, Q)) { return f(ne, B, G, Dq, x, gmap, yE, ydir, s); }
    MFA_REQUIRE(!BLK, "pa_apply: the blocked pa_data layout needs a specialised (D1D,Q1D); (%d,%d) is not registered", D, Q);
    report_fallback(KIND ? "PADiffusionApply3D" : "PAMassApply3D", D, Q);
    if (ne == 0) { return 0; }
@@ -1166,7 +1204,10 @@ static int run_apply(int D, int Q, int64_t ne, const double *B, const double *G,
       if (int rc = check_hip(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                              "hipFuncSetAttribute")) { return rc; }
    }
-   kern<<<dim3((unsigned)ne), dim3(256), lds, s>>>(D, Q, ne, bg, Dq, x, gmap, yE, VecArgs{}, 0);
+   MFA_REQUIRE(!ydir || (GATHER && !ACCUM && D >= 3), "pa_apply: interior rows can only be written by the gather kernels, D1D >= 3");
+   VecArgs va{};
+   va.ydirect = ydir;
+   kern<<<dim3((unsigned)ne), dim3(256), lds, s>>>(D, Q, ne, bg, Dq, x, gmap, yE, va, 0);
    MFA_CHECK_LAUNCH("k_pa_apply_generic");
    return 0;
 }
@@ -1288,20 +1329,21 @@ int pa_apply_L2E_vec(int kind, int layout, int D, int Q, int64_t ne, const doubl
 }
 
 int pa_apply_L2E(int kind, int layout, int D, int Q, int64_t ne, const double *B, const double *G,
-                 const double *Dq, const int *gmap, const double *x, double *yE, hipStream_t s)
+                 const double *Dq, const int *gmap, const double *x, double *yE, hipStream_t s, double *ydir)
 {
    if (kind == 2)
    {
+      MFA_REQUIRE(!ydir, "pa_apply: the non-symmetric D (kind 2) writes the whole E-vector");
       MFA_REQUIRE(layout == 0, "pa_apply: the non-symmetric D (kind 2) has the MFEM layout only");
       return run_apply_nonsym<true, false>(D, Q, ne, B, G, Dq, x, gmap, yE, s);
    }
    if (layout)
    {
-      if (kind == 0) { return run_apply<0, true, false, true>(D, Q, ne, B, G, Dq, x, gmap, yE, s); }
-      return run_apply<1, true, false, true>(D, Q, ne, B, G, Dq, x, gmap, yE, s);
+      if (kind == 0) { return run_apply<0, true, false, true>(D, Q, ne, B, G, Dq, x, gmap, yE, s, ydir); }
+      return run_apply<1, true, false, true>(D, Q, ne, B, G, Dq, x, gmap, yE, s, ydir);
    }
-   if (kind == 0) { return run_apply<0, true, false, false>(D, Q, ne, B, G, Dq, x, gmap, yE, s); }
-   return run_apply<1, true, false, false>(D, Q, ne, B, G, Dq, x, gmap, yE, s);
+   if (kind == 0) { return run_apply<0, true, false, false>(D, Q, ne, B, G, Dq, x, gmap, yE, s, ydir); }
+   return run_apply<1, true, false, false>(D, Q, ne, B, G, Dq, x, gmap, yE, s, ydir);
 }
 
 } // namespace mfa
@@ -1337,9 +1379,20 @@ extern "C" int mfem_amd_pa_apply_L2E(int kind, int pa_layout, int D1D, int Q1D, 
 {
    MFA_REQUIRE(kind >= 0 && kind <= 2, "pa_apply_L2E: kind must be 0 (mass), 1 (diffusion) or 2 (diffusion, non-symmetric D)");
    MFA_REQUIRE(pa_layout == 0 || pa_layout == 1, "pa_apply_L2E: pa_layout must be 0 (MFEM) or 1 (blocked)");
-   return pa_apply_L2E(kind, pa_layout, D1D, Q1D, ne, B, G, D, gather_map, x, yE, as_stream(stream));
+   return pa_apply_L2E(kind, pa_layout, D1D, Q1D, ne, B, G, D, gather_map, x, yE, as_stream(stream), nullptr);
 }
 
+
+extern "C" int mfem_amd_pa_apply_L2E_direct(int kind, int pa_layout, int D1D, int Q1D, int64_t ne,
+                                            const double *B, const double *G, const double *D,
+                                            const int *gather_map, const double *x, double *yE,
+                                            double *y_interior, void *stream)
+{
+   MFA_REQUIRE(kind == 0 || kind == 1, "pa_apply_L2E_direct: kind must be 0 (mass) or 1 (diffusion)");
+   MFA_REQUIRE(pa_layout == 0 || pa_layout == 1, "pa_apply_L2E_direct: pa_layout must be 0 (MFEM) or 1 (blocked)");
+   MFA_REQUIRE(D1D >= 3 && y_interior, "pa_apply_L2E_direct: needs D1D >= 3 and the interior rows of y");
+   return pa_apply_L2E(kind, pa_layout, D1D, Q1D, ne, B, G, D, gather_map, x, yE, as_stream(stream), y_interior);
+}
 
 extern "C" int mfem_amd_pa_apply_L2E_vdim(int kind, int pa_layout, int D1D, int Q1D, int64_t ne,
                                           int vdim, int byvdim, int64_t ndofs,

@@ -256,12 +256,22 @@ k_scatter(const int64_t ndofs, const int *__restrict__ offsets,
           const int *__restrict__ indices, const double *__restrict__ xE,
           double *__restrict__ y, const unsigned char *__restrict__ marker,
           const double *__restrict__ xin, const double *__restrict__ w,
-          double *__restrict__ partials, const int *__restrict__ skip, const int flags)
+          double *__restrict__ partials, const int *__restrict__ skip, const int flags, const int64_t ndirect)
 {
    __shared__ double sval[SCAT_CAP];
    __shared__ double s4[4];
    if (skip && *skip) { return; }
    double prod = 0.0;
+   // rows ndofs .. ndofs + ndirect - 1 were written by the element kernel (element-interior dofs): nothing to sum,
+   // only their part of (w, y), streamed in a fixed thread order
+   if (DOT && ndirect > 0)
+   {
+      const double *yd = y;             // (read-only here; the rows this kernel writes are below ndofs)
+      for (int64_t i = ndofs + (int64_t)blockIdx.x*256 + threadIdx.x; i < ndofs + ndirect; i += (int64_t)gridDim.x*256)
+      {
+         prod += w[i]*yd[i];
+      }
+   }
    // Wave-uniform choice by the table's own average row length nnz/ndofs (profiles/r1/e2l_rows_probe.txt,
    // profiles/r2/e2l_blk_probe.txt): the block-cooperative form below 6 entries per row (p >= 2); long rows
    // (p = 1: 8 entries) overflow its LDS tile and are faster row per thread, 8 entries of two rows in flight.
@@ -276,7 +286,7 @@ k_scatter(const int64_t ndofs, const int *__restrict__ offsets,
    {
       // streamed-once operands non-temporal when the tables cannot stay in the Infinity Cache between applications
       // anyway (profiles/r2/e2l_nt_probe.txt); small problems keep everything cached
-      if ((flags & 4) && ndofs > 3000000) { scatter_block_rows<MODE, DOT, true>(ndofs, offsets, indices, xE, y, marker, xin, w, prod, sval, bid); }
+      if ((flags & 4) && ndofs + ndirect > 3000000) { scatter_block_rows<MODE, DOT, true>(ndofs, offsets, indices, xE, y, marker, xin, w, prod, sval, bid); }
       else { scatter_block_rows<MODE, DOT>(ndofs, offsets, indices, xE, y, marker, xin, w, prod, sval, bid); }
    }
    else if (nnz >= 3*ndofs) { scatter_rows<MODE, DOT, 8, 2>(ndofs, offsets, indices, xE, y, marker, xin, w, prod, bid); }
@@ -652,17 +662,17 @@ static int scatter_flags()
 // E->L with the fused dot; nblocks partials are written (fixed by the caller from n only).
 int scatter_dot(int64_t ndofs, const int *offsets, const int *indices, const double *xE,
                 double *y, const unsigned char *marker, const double *xin, const double *w,
-                double *partials, int nblocks, const int *skip, hipStream_t s)
+                double *partials, int nblocks, const int *skip, hipStream_t s, int64_t ndirect)
 {
    if (w)
    {
       k_scatter<0, true><<<dim3(nblocks), dim3(256), 0, s>>>(ndofs, offsets, indices, xE, y,
-                                                           marker, xin, w, partials, skip, scatter_flags());
+                                                           marker, xin, w, partials, skip, scatter_flags(), ndirect);
    }
    else
    {
       k_scatter<0, false><<<dim3(nblocks), dim3(256), 0, s>>>(ndofs, offsets, indices, xE, y,
-                                                            marker, xin, nullptr, nullptr, skip, scatter_flags());
+                                                            marker, xin, nullptr, nullptr, skip, scatter_flags(), 0);
    }
    MFA_CHECK_LAUNCH("k_scatter");
    return 0;
@@ -745,19 +755,60 @@ extern "C" int mfem_amd_restrict_scatter(int64_t ndofs, const int *offsets, cons
    if (absv)
    {
       k_scatter<2, false><<<dim3(nb), dim3(256), 0, s>>>(ndofs, offsets, indices, xE, y, nullptr,
-                                                       nullptr, nullptr, nullptr, nullptr, scatter_flags());
+                                                       nullptr, nullptr, nullptr, nullptr, scatter_flags(), 0);
    }
    else if (add)
    {
       k_scatter<1, false><<<dim3(nb), dim3(256), 0, s>>>(ndofs, offsets, indices, xE, y, nullptr,
-                                                       nullptr, nullptr, nullptr, nullptr, scatter_flags());
+                                                       nullptr, nullptr, nullptr, nullptr, scatter_flags(), 0);
    }
    else
    {
       k_scatter<0, false><<<dim3(nb), dim3(256), 0, s>>>(ndofs, offsets, indices, xE, y, nullptr,
-                                                       nullptr, nullptr, nullptr, nullptr, scatter_flags());
+                                                       nullptr, nullptr, nullptr, nullptr, scatter_flags(), 0);
    }
    MFA_CHECK_LAUNCH("k_scatter");
+   return 0;
+}
+
+// Are the last ne*(D-2)^3 L-rows the element-interior dofs, element by element in lexicographic order, each
+// owned by its element alone?  (True of every H1 space numbered as the reference numbers it: vertex, edge, face,
+// then interior dofs, fem/fespace.cpp; the gather map is then gmap[e*D^3 + i(iz+1,iy+1,ix+1)] = I0 + e*NI + li.)
+__global__ void __launch_bounds__(256)
+k_interior_rows_check(const int D, const int64_t ne, const int64_t ndofs, const int *__restrict__ gmap,
+                      const int *__restrict__ offsets, int *__restrict__ bad)
+{
+   const int DI = D - 2, NI = DI*DI*DI, D3 = D*D*D;
+   const int64_t total = ne*NI, i0 = ndofs - total;
+   for (int64_t idx = (int64_t)blockIdx.x*256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x*256)
+   {
+      const int64_t e = idx/NI;
+      const int li = (int)(idx - e*NI);
+      const int ix = li % DI, iy = (li/DI) % DI, iz = li/(DI*DI);
+      const int64_t row = gmap[e*D3 + ((iz + 1)*D + (iy + 1))*D + (ix + 1)];
+      bool ok = row == i0 + idx;
+      if (ok) { ok = offsets[row + 1] - offsets[row] == 1; }
+      if (!ok) { atomicOr(bad, 1); }
+   }
+}
+
+extern "C" int mfem_amd_interior_rows(int D1D, int64_t ne, int64_t ndofs, const int *gather_map,
+                                      const int *offsets, int *work, int64_t *direct_rows, void *stream)
+{
+   MFA_REQUIRE(direct_rows, "interior_rows: direct_rows is NULL");
+   *direct_rows = 0;
+   if (D1D < 3 || ne <= 0) { return 0; }
+   MFA_REQUIRE(D1D <= MAX_D1D && ndofs > 0 && gather_map && offsets && work, "interior_rows: bad arguments");
+   const int64_t ni = (int64_t)(D1D - 2)*(D1D - 2)*(D1D - 2);
+   if (ne*ni > ndofs) { return 0; }
+   hipStream_t s = as_stream(stream);
+   if (int rc = check_hip(hipMemsetAsync(work, 0, sizeof(int), s), "hipMemsetAsync")) { return rc; }
+   k_interior_rows_check<<<dim3(grid_for(ne*ni)), dim3(256), 0, s>>>(D1D, ne, ndofs, gather_map, offsets, work);
+   MFA_CHECK_LAUNCH("k_interior_rows_check");
+   int bad = 1;
+   if (int rc = check_hip(hipMemcpyAsync(&bad, work, sizeof(int), hipMemcpyDeviceToHost, s), "hipMemcpyAsync")) { return rc; }
+   if (int rc = check_hip(hipStreamSynchronize(s), "hipStreamSynchronize")) { return rc; }
+   if (!bad) { *direct_rows = ne*ni; }
    return 0;
 }
 

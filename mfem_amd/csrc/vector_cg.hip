@@ -27,10 +27,10 @@ int scatter_dot_vec(int64_t ndofs, int nd, int vd, int byvdim, const int *offset
                     const double *xE, double *y, const unsigned char *marker, const double *xin,
                     const double *w, double *partials, int nblocks, const int *skip, hipStream_t s);
 int pa_apply_L2E(int kind, int layout, int D, int Q, int64_t ne, const double *B, const double *G,
-                 const double *Dq, const int *gmap, const double *x, double *yE, hipStream_t s);
+                 const double *Dq, const int *gmap, const double *x, double *yE, hipStream_t s, double *ydir);
 int scatter_dot(int64_t ndofs, const int *offsets, const int *indices, const double *xE,
                 double *y, const unsigned char *marker, const double *xin, const double *w,
-                double *partials, int nblocks, const int *skip, hipStream_t s);
+                double *partials, int nblocks, const int *skip, hipStream_t s, int64_t ndirect);
 
 static inline int red_blocks(int64_t n)
 {
@@ -450,9 +450,22 @@ static int constrained_mult(const mfem_amd_pa_operator *op, const mfem_amd_comm 
    }
    // NOTE: the element kernel is not gated by `skip`: after convergence it only rewrites
    // the work E-vector, and the gated transpose-gather leaves y untouched.
-   if (int rc = pa_apply_L2E(op->kind, op->pa_layout, op->D1D, op->Q1D, op->ne, op->B, op->G, op->pa_data, gm, x, op->yE, s)) { return rc; }
-   if (int rc = scatter_dot(op->ndofs, op->offsets, op->indices, op->yE, y, ess ? op->ess_marker : nullptr,
-                            x, w, partials, nb, skip, s)) { return rc; }
+   // Element-interior rows (the last direct_rows ones, mfem_amd_interior_rows) are written by the element kernel itself and
+   // the transpose-gather sums the rows before them -- where that pays (profiles/r2/direct_rows.txt): the direct stores
+   // are short runs (D-2 doubles) that complete each other's cache lines only while y stays in the 256 MiB Infinity
+   // Cache, so not above 3.3e7 dofs, and not inside the solver loop (w given), where five more vectors share that cache
+   // and the element kernel loses 28 us to gain 10 us in the transpose-gather.  MFEM_AMD_DIRECT=0 never, 2 always.
+   const char *pol = getenv("MFEM_AMD_DIRECT");
+   const int policy = pol ? atoi(pol) : 1;
+   const bool pays = policy == 2 || (policy == 1 && !w && op->ndofs*(int64_t)sizeof(double) <= ((int64_t)256 << 20));
+   const int64_t nd = (op->direct_rows > 0 && op->kind != 2 && pays) ? op->direct_rows : 0;
+   MFA_REQUIRE(nd >= 0 && nd <= op->ndofs, "pa operator: direct_rows out of range");
+   const int64_t nrows = op->ndofs - nd;
+   if (nd && !w) { nb = (int)((nrows + 1023)/1024 > 0 ? (nrows + 1023)/1024 : 1); }
+   if (int rc = pa_apply_L2E(op->kind, op->pa_layout, op->D1D, op->Q1D, op->ne, op->B, op->G, op->pa_data, gm, x, op->yE, s,
+                             nd ? y + nrows : nullptr)) { return rc; }
+   if (int rc = scatter_dot(nrows, op->offsets, op->indices, op->yE, y, ess ? op->ess_marker : nullptr,
+                            x, w, partials, nb, skip, s, nd)) { return rc; }
    if (comm)
    {
       if (int rc = comm->reverse(comm->ctx, y, (void*)s)) { set_error("comm reverse exchange failed (%d)", rc); return rc; }
@@ -469,6 +482,26 @@ extern "C" int mfem_amd_pa_constrained_mult(const mfem_amd_pa_operator *op, cons
    const unsigned nb = (unsigned)((n + 255)/256);
    if (n == 0) { return 0; }
    return constrained_mult(op, nullptr, const_cast<double*>(x), y, nullptr, nullptr, (int)nb, nullptr, as_stream(stream));
+}
+
+extern "C" int mfem_amd_pa_apply_L2L(int kind, int pa_layout, int D1D, int Q1D, int64_t ne, int64_t ndofs,
+                                     const double *B, const double *G, const double *D, const int *gather_map,
+                                     const int *offsets, const int *indices, int64_t direct_rows,
+                                     const double *x, double *yE, double *y, void *stream)
+{
+   MFA_REQUIRE(kind == 0 || kind == 1, "pa_apply_L2L: kind must be 0 (mass) or 1 (diffusion)");
+   MFA_REQUIRE(pa_layout == 0 || pa_layout == 1, "pa_apply_L2L: pa_layout must be 0 (MFEM) or 1 (blocked)");
+   MFA_REQUIRE(ne >= 0 && ndofs >= 0 && direct_rows >= 0 && direct_rows <= ndofs, "pa_apply_L2L: bad sizes");
+   MFA_REQUIRE(x && y && yE && x != y && offsets && indices && gather_map, "pa_apply_L2L: bad arguments");
+   MFA_REQUIRE(direct_rows == 0 || (D1D >= 3 && direct_rows == ne*(int64_t)(D1D - 2)*(D1D - 2)*(D1D - 2)),
+               "pa_apply_L2L: direct_rows must be 0 or NE*(D1D-2)^3 (mfem_amd_interior_rows)");
+   if (ndofs == 0) { return 0; }
+   mfem_amd_pa_operator op = {};
+   op.kind = kind; op.pa_layout = pa_layout; op.D1D = D1D; op.Q1D = Q1D; op.ne = ne; op.ndofs = ndofs;
+   op.B = B; op.G = G; op.pa_data = D; op.gather_map = gather_map; op.offsets = offsets; op.indices = indices;
+   op.yE = yE; op.direct_rows = direct_rows;
+   const int64_t nb = (ndofs + 1023)/1024;
+   return constrained_mult(&op, nullptr, const_cast<double*>(x), y, nullptr, nullptr, (int)nb, nullptr, as_stream(stream));
 }
 
 extern "C" int mfem_amd_pa_par_mult(const mfem_amd_pa_operator *op, const mfem_amd_comm *comm,

@@ -263,6 +263,25 @@ ElementRestriction::ElementRestriction(const FiniteElementSpace &f, ElementDofOr
    }
    for (int i = ndofs; i > 0; --i) { off[i] = off[i - 1]; }
    off[0] = 0;
+   // element-interior dofs last, element by element, lexicographic, one entry each?
+   int D = 2;
+   while (D*D*D < dof) { ++D; }
+   if (D*D*D == dof && D >= 3)
+   {
+      const int DI = D - 2, NI = DI*DI*DI;
+      const long long i0 = (long long)ndofs - (long long)ne*NI;
+      bool ok = i0 >= 0;
+      for (int e = 0; ok && e < ne; ++e)
+      {
+         for (int li = 0; ok && li < NI; ++li)
+         {
+            const int ix = li % DI, iy = (li/DI) % DI, iz = li/(DI*DI);
+            const int row = gm[(long long)e*dof + ((iz + 1)*D + (iy + 1))*D + (ix + 1)];
+            ok = row == i0 + (long long)e*NI + li && off[row + 1] - off[row] == 1;
+         }
+      }
+      direct_rows = ok ? (long long)ne*NI : 0;
+   }
 }
 void ElementRestriction::Mult(const Vector &x, Vector &y) const
 {
@@ -922,6 +941,7 @@ bool PABilinearFormExtension::FillOperator(mfem_amd_pa_operator &op) const
    op.gather_map = R->GatherMap().Read(); op.masked_gather_map = op.gather_map;
    op.offsets = R->Offsets().Read(); op.indices = R->Indices().Read();
    op.yE = localY.Write();
+   op.direct_rows = op.vdim == 0 ? R->DirectRows() : 0;
    return true;
 }
 

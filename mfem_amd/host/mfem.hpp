@@ -848,8 +848,12 @@ class ElementRestriction : public Operator
    const FiniteElementSpace &fes;
    int ne, vdim, ndofs, dof; bool byvdim;
    Array<int> offsets, indices, gather_map;
+   long long direct_rows = 0;
 public:
    ElementRestriction(const FiniteElementSpace &, ElementDofOrdering);
+   /// NE*(D1D-2)^3 when the last L-dofs are the element-interior dofs, element by element in lexicographic order (the
+   /// native H1 numbering puts them there), else 0: rows the PA element kernel writes itself (mfem_amd_interior_rows)
+   long long DirectRows() const { return direct_rows; }
    void Mult(const Vector &x, Vector &y) const override;
    void MultTranspose(const Vector &x, Vector &y) const override;
    void AddMultTranspose(const Vector &x, Vector &y, const real_t a = 1.0) const;
