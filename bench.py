@@ -97,7 +97,7 @@ def main():
         total_dofs = int(owned.item())
     else:
         transport = None
-        bp = BakeoffProblem(args.problem, p, (n, n, n), dev, numbering=numbering_for((p*n + 1)**3))
+        bp = BakeoffProblem(args.problem, p, (n, n, n), dev, numbering=numbering_for((p*n + 1)**3, p))
         total_dofs = bp.ndofs
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
@@ -237,7 +237,7 @@ def main():
                                       f"D1D={D} Q1D={Q}, Cartesian hex mesh {n}^3 per GPU",
                           "elements_per_gpu": ne, "local_dofs_per_gpu": ndofs, "global_dofs": total_dofs,
                           "process_grid": list(pg), "transport": transport,
-                          "numbering": numbering_for(ndofs) if world == 1 else "lexicographic",
+                          "numbering": numbering_for(ndofs, p) if world == 1 else "lexicographic",
                           "element_interior_rows_written_by_element_kernel": int(getattr(bp_direct, "v", 0))},
                "roofline": roof, "roofline_apply": roof_apply, "graph_replay": replay, "cg": cg, "by_order": by_order, "by_size": by_size,
                "cpu_baseline": cpu,
@@ -254,10 +254,10 @@ def main():
 NUMBERING = os.environ.get("MFEM_AMD_BENCH_NUMBERING", "interior-last")
 
 
-def numbering_for(ndofs):
-    """interior-last where the library uses it (y within the Infinity Cache: vector_cg.hip, constrained_mult); above that
-    the plain grid numbering, whose gathers are the more local ones (profiles/r2/direct_rows.txt)"""
-    return NUMBERING if ndofs*8 <= (256 << 20) else "lexicographic"
+def numbering_for(ndofs, p):
+    """interior-last where the library uses it (p >= 4 and y within the Infinity Cache: vector_cg.hip, constrained_mult);
+    elsewhere the plain grid numbering, whose gathers are the more local ones (profiles/r2/direct_rows.txt)"""
+    return NUMBERING if p >= 4 and ndofs*8 <= (256 << 20) else "lexicographic"
 
 
 def spin_count(nbytes):
@@ -347,7 +347,7 @@ def size_row(problem, p, dofs, dev, gen, cg_iters=20):
     import torch
     from mfem_amd.bp import BakeoffProblem
     n = max(1, round(dofs**(1.0/3.0)/p))
-    bq = BakeoffProblem(problem, p, (n, n, n), dev, device_tables=True, numbering=numbering_for((p*n + 1)**3))
+    bq = BakeoffProblem(problem, p, (n, n, n), dev, device_tables=True, numbering=numbering_for((p*n + 1)**3, p))
     xq = torch.rand(bq.ndofs, dtype=torch.float64, generator=gen).to(dev)
     yq = torch.empty_like(xq)
     b1, b2 = algorithmic_bytes(bq.kind, bq.D, bq.Q, bq.ne, bq.ndofs)
@@ -386,7 +386,7 @@ def size_row(problem, p, dofs, dev, gen, cg_iters=20):
     tl = sorted(ev_time(lambda: bq.l2e(xq, y=yq), 20) for _ in range(3))[1]/20
     row = {"problem": problem, "p": p, "n": n, "dofs": bq.ndofs, "GDOF/s": bq.ndofs/tq/1e9, "ms_per_step": tq*1e3,
            "apply_frac": (b1 + b2)/tq/1e9/HBM_PEAK_GBS, "l2e_ms": tl*1e3, "l2e_frac": b1/tl/1e9/HBM_PEAK_GBS,
-           "launch": f"hip graph of {k} applies" if graph else "eager", "numbering": numbering_for(bq.ndofs),
+           "launch": f"hip graph of {k} applies" if graph else "eager", "numbering": numbering_for(bq.ndofs, p),
            "interior_rows_direct": bq.direct if bq.direct_active() else 0}
     if cg_iters > 0:
         rhs = torch.rand(bq.ndofs, dtype=torch.float64, generator=gen).to(dev)

@@ -149,7 +149,7 @@ class BakeoffProblem:
     def direct_active(self):
         """does mult() write the element-interior rows from the element kernel? (vector_cg.hip: constrained_mult)"""
         pol = int(os.environ.get("MFEM_AMD_DIRECT", "1"))
-        return bool(self.direct) and (pol == 2 or (pol == 1 and self.nscalar*8 <= (256 << 20)))
+        return bool(self.direct) and (pol == 2 or (pol == 1 and self.D >= 5 and self.nscalar*8 <= (256 << 20)))
 
     def l2e(self, x, e0=0, e1=None, y=None):
         """element kernel over the elements [e0, e1) (e0 on a batch boundary of the blocked layout); with y, and where

@@ -454,10 +454,11 @@ static int constrained_mult(const mfem_amd_pa_operator *op, const mfem_amd_comm 
    // the transpose-gather sums the rows before them -- where that pays (profiles/r2/direct_rows.txt): the direct stores
    // are short runs (D-2 doubles) that complete each other's cache lines only while y stays in the 256 MiB Infinity
    // Cache, so not above 3.3e7 dofs, and not inside the solver loop (w given), where five more vectors share that cache
-   // and the element kernel loses 28 us to gain 10 us in the transpose-gather.  MFEM_AMD_DIRECT=0 never, 2 always.
+   // and the element kernel loses 28 us to gain 10 us in the transpose-gather; and not below p = 4, where an element has
+   // 1 or 8 interior dofs and the rows saved do not pay for the second store stream.  MFEM_AMD_DIRECT=0 never, 2 always.
    const char *pol = getenv("MFEM_AMD_DIRECT");
    const int policy = pol ? atoi(pol) : 1;
-   const bool pays = policy == 2 || (policy == 1 && !w && op->ndofs*(int64_t)sizeof(double) <= ((int64_t)256 << 20));
+   const bool pays = policy == 2 || (policy == 1 && !w && op->D1D >= 5 && op->ndofs*(int64_t)sizeof(double) <= ((int64_t)256 << 20));
    const int64_t nd = (op->direct_rows > 0 && op->kind != 2 && pays) ? op->direct_rows : 0;
    MFA_REQUIRE(nd >= 0 && nd <= op->ndofs, "pa operator: direct_rows out of range");
    const int64_t nrows = op->ndofs - nd;

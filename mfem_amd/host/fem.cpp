@@ -757,6 +757,17 @@ void PABilinearFormExtension::Mult(const Vector &x, Vector &y) const
                                                bfi->maps->B.HostRead(), bfi->maps->G.HostRead(), bfi->pa_data.Read(), bfi->pa_comp_stride,
                                                elem_restrict->GatherMap().Read(), nullptr, x.Read(), localY.Write(), nullptr));
    }
+   else if (const BilinearFormIntegrator *bfi = SingleIntegrator(); bfi && bfi->OperatorKind() != 2 && x.Read() != y.Read())
+   {
+      // both halves in one call: the element-interior rows (the native numbering puts them last) go from the element
+      // kernel straight to y, the transpose sums the rows before them (include/mfem_amd.h: mfem_amd_interior_rows)
+      MFEM_AMD_CALL(mfem_amd_pa_apply_L2L(bfi->OperatorKind(), bfi->pa_layout, bfi->dofs1D, bfi->quad1D, bfi->ne, fes->GetNDofs(),
+                                          bfi->maps->B.HostRead(), bfi->maps->G.HostRead(), bfi->pa_data.Read(),
+                                          elem_restrict->GatherMap().Read(), elem_restrict->Offsets().Read(),
+                                          elem_restrict->Indices().Read(), elem_restrict->DirectRows(), x.Read(),
+                                          localY.Write(), y.Write(), nullptr));
+      return;
+   }
    else if (const BilinearFormIntegrator *bfi = SingleIntegrator())
    {
       // gather fused into the element kernel: no localX, no memset of localY

@@ -32,12 +32,13 @@ def interior_rows(gh, D, ne, ndofs, gm, off):
 
 
 @pytest.mark.parametrize("name", CASES)
-def test_golden_meshes_direct_rows_bit_identical(gh, name):
+def test_golden_meshes_direct_rows_bit_identical(gh, name, monkeypatch):
     """The reference's own numbering (the golden cases were dumped from it): the probe finds the interior rows of every
     case with D1D >= 3, and the constrained operator with them written directly equals the plain form, both layouts."""
     from mfem_amd import capi
     c = load_case(name)
     D, NE, n = c["D1D"], c["NE"], c["ndofs"]
+    monkeypatch.setenv("MFEM_AMD_DIRECT", "2")       # every shape, not only where the default policy uses it (D1D >= 5)
     for layout in (0, 1):
         if layout and not (capi.lib.mfem_amd_has_specialization(c["kind"], D, c["Q1D"]) and NE % 2 == 0):
             continue
@@ -77,6 +78,7 @@ def test_interior_last_numbering_matches_lexicographic(gh, problem, p, n, monkey
     xl = torch.rand(lex.ndofs, dtype=torch.float64, generator=g).to(dev)
     xi = torch.empty_like(xl); xi[il.perm] = xl
     yl, yi, y0 = torch.empty_like(xl), torch.full_like(xl, float("nan")), torch.empty_like(xl)
+    monkeypatch.setenv("MFEM_AMD_DIRECT", "2")       # every order, not only where the default policy uses it (p >= 4)
     lex.mult(xl, yl); il.mult(xi, yi); il0.mult(xi, y0)
     torch.cuda.synchronize()
     assert torch.equal(yi, y0)                       # direct rows vs the plain form, same numbering: same bits
@@ -87,6 +89,11 @@ def test_interior_last_numbering_matches_lexicographic(gh, problem, p, n, monkey
     bi[il.ess.long()] = 0.0
     # (by default the solver loop keeps the E-vector route -- vector_cg.hip: constrained_mult; MFEM_AMD_DIRECT=2 makes it
     # write the interior rows directly and take their part of (d, A d) in the transpose-gather kernel)
+    monkeypatch.delenv("MFEM_AMD_DIRECT")
+    yd = torch.full_like(xl, float("nan"))
+    il.mult(xi, yd)                                  # default policy
+    torch.cuda.synchronize()
+    assert torch.equal(yd, y0)
     X3, r3, h3 = il.pcg(bi, 1e-8, max_iter=400, check_every=3, want_hist=True)
     monkeypatch.setenv("MFEM_AMD_DIRECT", "2")
     X1, r1, h1 = il.pcg(bi, 1e-8, max_iter=400, check_every=3, want_hist=True)
