@@ -211,6 +211,16 @@ __device__ __forceinline__ void pcg_beta_step(PcgState *st, const double betanom
 
 // kernel A: r -= alpha z; z = dinv.r (or r); partial (r, z).  (x += alpha d rides with kernel B, which reads d
 // anyway: one pass over d less per iteration, the same x bit for bit.)
+// NT (large solves, pcg_nt): the vectors that are touched once per iteration (r, dinv here; x in kernel B) go past
+// the caches, so that the two the next kernels read again -- z, then d -- are what the 256 MiB Infinity Cache holds
+template <bool NT> __device__ __forceinline__ double ld_stream(const double *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT> __device__ __forceinline__ void st_stream(double *p, const double v)
+{
+   if (NT) { __builtin_nontemporal_store(v, p); }
+   else { *p = v; }
+}
+
+template <bool NT>
 __global__ void __launch_bounds__(256)
 k_pcg_update(const int64_t n, const PcgState *__restrict__ st, const double *__restrict__ dinv,
              double *__restrict__ r, double *__restrict__ z, double *__restrict__ partials)
@@ -221,9 +231,9 @@ k_pcg_update(const int64_t n, const PcgState *__restrict__ st, const double *__r
    double acc = 0.0;
    for (int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x; i < n; i += (int64_t)gridDim.x*256)
    {
-      const double ri = r[i] + (-alpha)*z[i];
-      const double zi = dinv ? dinv[i]*ri : ri;
-      r[i] = ri; z[i] = zi;
+      const double ri = ld_stream<NT>(&r[i]) + (-alpha)*z[i];
+      const double zi = dinv ? ld_stream<NT>(&dinv[i])*ri : ri;
+      st_stream<NT>(&r[i], ri); z[i] = zi;
       acc += ri*zi;
    }
    const double s = block_sum_256(acc, s4);
@@ -244,6 +254,7 @@ k_pcg_beta_scalars(const int nb, const double *__restrict__ partials, PcgState *
 // kernel B: x += alpha d (the update of the iteration whose kernel A just ran: the reference updates x before it
 // tests convergence, linalg/solvers.cpp:957-958, so the last iteration's update is applied as well); then, unless
 // the solve has ended, d = z + beta d.  Launches after the end change nothing.
+template <bool NT>
 __global__ void __launch_bounds__(256)
 k_pcg_dir(const int64_t n, const PcgState *__restrict__ st, const double *__restrict__ z,
           double *__restrict__ d, double *__restrict__ x)
@@ -262,8 +273,8 @@ k_pcg_dir(const int64_t n, const PcgState *__restrict__ st, const double *__rest
    for (int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x; i < n; i += (int64_t)gridDim.x*256)
    {
       const double di = d[i];
-      x[i] = x[i] + alpha*di;
-      d[i] = z[i] + beta*di;
+      st_stream<NT>(&x[i], ld_stream<NT>(&x[i]) + alpha*di);
+      d[i] = ld_stream<NT>(&z[i]) + beta*di;          // (z is dead after this read: the next apply overwrites it)
    }
 }
 
@@ -415,6 +426,8 @@ extern "C" int mfem_amd_jacobi_apply(int64_t n, const double *dinv, const double
 // ghost entries of x from their owners, reverse = P^T adds the ghost entries of y into the
 // owners and zeroes them.  The (w, y) partials are taken BEFORE the reverse exchange, over
 // all local dofs: sum_ranks (P w)^T A_L (P w) = w^T P^T A P w.
+static bool pcg_nt(int64_t n);
+
 static int constrained_mult(const mfem_amd_pa_operator *op, const mfem_amd_comm *comm,
                             double *x, double *y, const double *w, double *partials, int nb,
                             const int *skip, hipStream_t s)
@@ -453,12 +466,14 @@ static int constrained_mult(const mfem_amd_pa_operator *op, const mfem_amd_comm 
    // Element-interior rows (the last direct_rows ones, mfem_amd_interior_rows) are written by the element kernel itself and
    // the transpose-gather sums the rows before them -- where that pays (profiles/r2/direct_rows.txt): the direct stores
    // are short runs (D-2 doubles) that complete each other's cache lines only while y stays in the 256 MiB Infinity
-   // Cache, so not above 3.3e7 dofs, and not inside the solver loop (w given), where five more vectors share that cache
-   // and the element kernel loses 28 us to gain 10 us in the transpose-gather; and not below p = 4, where an element has
-   // 1 or 8 interior dofs and the rows saved do not pay for the second store stream.  MFEM_AMD_DIRECT=0 never, 2 always.
+   // Cache, so not above 3.3e7 dofs; inside the solver loop (w given) only together with the solver's streaming policy
+   // (pcg_nt: with x, r and dinv cached too the element kernel lost 28 us to gain 10 us in the transpose-gather; with them
+   // out of the cache p = 4 gains 0.4 %, p = 6 3.2 %); and not below p = 4, where an element has 1 or 8 interior dofs and
+   // the rows saved do not pay for the second store stream.  MFEM_AMD_DIRECT=0 never, 2 always.
    const char *pol = getenv("MFEM_AMD_DIRECT");
    const int policy = pol ? atoi(pol) : 1;
-   const bool pays = policy == 2 || (policy == 1 && !w && op->D1D >= 5 && op->ndofs*(int64_t)sizeof(double) <= ((int64_t)256 << 20));
+   const bool pays = policy == 2 || (policy == 1 && op->D1D >= 5 && op->ndofs*(int64_t)sizeof(double) <= ((int64_t)256 << 20) &&
+                                     (!w || pcg_nt(op->ndofs)));
    const int64_t nd = (op->direct_rows > 0 && op->kind != 2 && pays) ? op->direct_rows : 0;
    MFA_REQUIRE(nd >= 0 && nd <= op->ndofs, "pa operator: direct_rows out of range");
    const int64_t nrows = op->ndofs - nd;
@@ -522,6 +537,15 @@ extern "C" int64_t mfem_amd_pcg_workspace_bytes(int64_t n, int max_iter)
           align_up(((int64_t)max_iter + 2)*8, 256) + 256 + 256;
 }
 
+// the streaming policy of the solver's vector kernels: MFEM_AMD_PCG_NT=0|1 forces it; by default on once the solver's
+// six vectors (x, r, d, z, dinv, b) cannot all stay in the Infinity Cache anyway
+static bool pcg_nt(int64_t n)
+{
+   const char *e = getenv("MFEM_AMD_PCG_NT");
+   if (e && (e[0] == '0' || e[0] == '1')) { return e[0] == '1'; }
+   return n*(int64_t)sizeof(double)*6 > ((int64_t)256 << 20);
+}
+
 static int pcg_impl(const mfem_amd_pa_operator *op, const mfem_amd_comm *comm, const double *dinv,
                     const double *b, double *x, double rel_tol, double abs_tol, int max_iter,
                     int check_every, void *workspace, mfem_amd_pcg_result *result, double *hist,
@@ -575,6 +599,7 @@ static int pcg_impl(const mfem_amd_pa_operator *op, const mfem_amd_comm *comm, c
    // folding the scalar steps into the prologues of the kernels that consume them were both measured and
    // rejected: profiles/r2/pcg_fused_finish_probe.txt.)
    const int total = max_iter > 0 ? max_iter : 1;
+   const bool nt = pcg_nt(n);
    PcgState cur;
    int launched = 0;
    while (true)
@@ -587,10 +612,12 @@ static int pcg_impl(const mfem_amd_pa_operator *op, const mfem_amd_comm *comm, c
       const TraceRange batch_range("mfem_amd: PCG iterations (one host poll)");
       for (int k = 0; k < batch; k++)
       {
-         k_pcg_update<<<dim3(nb), dim3(256), 0, s>>>(n, st, dinv, r, z, partials);
+         if (nt) { k_pcg_update<true><<<dim3(nb), dim3(256), 0, s>>>(n, st, dinv, r, z, partials); }
+         else { k_pcg_update<false><<<dim3(nb), dim3(256), 0, s>>>(n, st, dinv, r, z, partials); }
          if (int rc = global_sum()) { return rc; }
          k_pcg_beta_scalars<<<dim3(1), dim3(256), 0, s>>>(nb, partials, st, dhist, gs);
-         k_pcg_dir<<<dim3(sg), dim3(256), 0, s>>>(n, st, z, d, x);
+         if (nt) { k_pcg_dir<true><<<dim3(sg), dim3(256), 0, s>>>(n, st, z, d, x); }
+         else { k_pcg_dir<false><<<dim3(sg), dim3(256), 0, s>>>(n, st, z, d, x); }
          MFA_CHECK_LAUNCH("pcg iteration kernels");
          if (int rc = constrained_mult(op, comm, d, z, d, partials, nb, &st->done, s)) { return rc; }
          if (int rc = global_sum()) { return rc; }

@@ -186,6 +186,30 @@ def test_constrained_operator_and_pcg(gh, name):
     assert np.array_equal(gh.host(X1), gh.host(X2)) and np.array_equal(h1, h2)
 
 
+@pytest.mark.parametrize("name", CASES[:4])
+def test_pcg_streaming_policy_is_bit_identical(gh, name, monkeypatch):
+    """Large solves load and store x, r and dinv non-temporally in the solver's vector kernels (vector_cg.hip: pcg_nt,
+    on by default above 5.6e6 unknowns); MFEM_AMD_PCG_NT forces the choice.  A cache policy: same bits, counts, history."""
+    from mfem_amd import capi
+    c = load_case(name)
+    n, ess = c["ndofs"], c["ess_tdof"]
+    op = gh.DeviceOperator(c, ess)
+    diag, dinv = gh.dev(c["diag"]), gh.zeros(n)
+    capi.call("mfem_amd_jacobi_setup", n, gh.ptr(diag), 1.0, len(ess), gh.ptr(op.ess), gh.ptr(dinv), None)
+    rel_tol = 1e-10 if c["kind"] == 0 else 1e-6
+    b = gh.dev(c["B_rhs"])
+    out = {}
+    for nt in ("0", "1"):
+        monkeypatch.setenv("MFEM_AMD_PCG_NT", nt)
+        for jac in (dinv, None):
+            X, r, h = op.pcg(b, jac, rel_tol, max_iter=300, check_every=4)
+            out[nt, jac is None] = (gh.host(X), r.iterations, r.converged, r.final_nom, h)
+    for key in (False, True):
+        a, bb = out["0", key], out["1", key]
+        assert np.array_equal(a[0], bb[0]) and a[1:4] == bb[1:4] and np.array_equal(a[4], bb[4])
+    assert out["1", False][1] == c["cg_iters"]
+
+
 def test_pcg_curvature_breakdown_counts(gh):
     """(A d, d) = 0: CGSolver::Mult leaves with converged = false (linalg/solvers.cpp:930-940 at iteration 0,
     :1011-1025 inside the loop, where the count has been advanced past the last residual it printed).
