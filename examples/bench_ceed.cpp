@@ -84,6 +84,14 @@ static void run_case(int bp, int p, int N)
    a.Mult(x, y);
    const double ynorm = y.Norml2();
    x.Read(); y.Write();
+   // the device needs 25-35 ms of continuous work after any idle period to reach its steady rate
+   // (profiles/r2/warmup_probe.txt): ~0.1 s of the same applies, untimed, before the timed ones
+   {
+      const double D1w = p + 1, Q1w = ir->n1d;
+      const double bw = (double)mesh.GetNE()*((mass ? 1 : 6)*Q1w*Q1w*Q1w*8 + 2*D1w*D1w*D1w*4) + 20.0*dofs;
+      const int spin = (int)std::min(4000.0, std::max(10.0, std::ceil(0.1/(bw/3.0e12))));
+      for (int i = 0; i < spin; i++) { a.Mult(x, y); }
+   }
    internal::DeviceSync();
    t0 = now();
    for (int i = 0; i < reps; i++) { a.Mult(x, y); }

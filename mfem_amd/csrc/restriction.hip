@@ -276,11 +276,11 @@ k_scatter(const int64_t ndofs, const int *__restrict__ offsets,
    // profiles/r2/e2l_blk_probe.txt): the block-cooperative form below 6 entries per row (p >= 2); long rows
    // (p = 1: 8 entries) overflow its LDS tile and are faster row per thread, 8 entries of two rows in flight.
    const int64_t nnz = offsets[ndofs];
-   // Logical block id XCD-contiguous (the partial sums stay indexed by the logical id: same bits): where rows are
-   // long but still go through the block form (p = 2: 3.4 entries per row) the row blocks of one XCD then share their
-   // E-vector lines in that XCD's L2 -- 2.7 % on the whole apply at p = 2, neutral or slightly worse elsewhere
-   // (profiles/r2/xcd_probe.txt).  flags & 1 forces it everywhere (tuning aid).
-   const bool xcd = (flags & 1) || (!(flags & 2) && nnz >= 3*ndofs && nnz < 6*ndofs);
+   // Logical block id XCD-contiguous (the partial sums stay indexed by the logical id: same bits): a tuning aid only
+   // (MFEM_AMD_SCATTER_XCD=1).  On the tensor-grid numbering of the synthetic boxes it gained 2.7 % at p = 2 and was
+   // adopted for 3..6 entries per row; on the reference's own numbering (C++ drivers) the same rule cost 27 % (BP3) and
+   // 58 % (BP1) at p = 2 -- profiles/r2/xcd_probe.txt -- so nothing selects it by default any more.
+   const bool xcd = (flags & 1) != 0;
    const int64_t bid = xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
    if (!(flags & 2) && nnz < 6*ndofs)
    {
