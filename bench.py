@@ -102,7 +102,7 @@ def main():
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
     kind, D, Q, ne, ndofs = bp.kind, bp.D, bp.Q, bp.ne, bp.ndofs
-    bp_direct = type("V", (), {"v": bp.direct})
+    n_direct = bp.direct if bp.direct_active() else 0      # (bp is deleted before the JSON line is written)
 
     g = torch.Generator(device="cpu"); g.manual_seed(1 + rank)
     x = torch.rand(ndofs, dtype=torch.float64, generator=g).to(dev)
@@ -238,7 +238,7 @@ def main():
                           "elements_per_gpu": ne, "local_dofs_per_gpu": ndofs, "global_dofs": total_dofs,
                           "process_grid": list(pg), "transport": transport,
                           "numbering": numbering_for(ndofs, p) if world == 1 else "lexicographic",
-                          "element_interior_rows_written_by_element_kernel": int(getattr(bp_direct, "v", 0))},
+                          "element_interior_rows_written_by_element_kernel": int(n_direct)},
                "roofline": roof, "roofline_apply": roof_apply, "graph_replay": replay, "cg": cg, "by_order": by_order, "by_size": by_size,
                "cpu_baseline": cpu,
                "setup_s": setup_s}
