@@ -58,8 +58,12 @@ def main():
     ap.add_argument("--no-orders", action="store_true", help="skip the p = 1..8 table (N=1 only; ~10 s)")
     ap.add_argument("--no-sizes", action="store_true", help="skip the BP1/BP3/BP5 x 1e5..1e8 dofs table (N=1 only; ~1 min)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cxx", action="store_true", help="skip the C++ driver legs (examples/bin/bench_ceed, p = 4, 5, 6; N=1 only)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: start the N ranks (one per GPU) before anything here touches the GPU
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -88,7 +92,8 @@ def main():
     pg = process_grid(world)
     t0 = time.perf_counter()
     if world > 1:
-        part = BoxPartition(p, (n, n, n), pg, rank)
+        # the same numbering class and therefore the same two kernels as at N = 1 (interior rows direct, packed E-vector)
+        part = BoxPartition(p, (n, n, n), pg, rank, numbering=NUMBERING)
         vd = 3 if args.problem in ("bp2", "bp4", "bp6") else 1
         ex, transport = make_exchange(part, dev, vd if vd > 1 else 0, rank, world)
         bp = BakeoffProblem(args.problem, p, (n, n, n), dev, part=part, exchange=ex)
@@ -97,7 +102,7 @@ def main():
         total_dofs = int(owned.item())
     else:
         transport = None
-        bp = BakeoffProblem(args.problem, p, (n, n, n), dev, numbering=numbering_for((p*n + 1)**3, p))
+        bp = BakeoffProblem(args.problem, p, (n, n, n), dev, device_tables=True, numbering=numbering_for((p*n + 1)**3, p))
         total_dofs = bp.ndofs
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
@@ -221,6 +226,13 @@ def main():
             for dofs in (1.0e5, 1.0e6, 1.0e7, 1.0e8):
                 by_size.append(size_row(prob, p, dofs, dev, g, cg_iters=20))
 
+    # the same problems through the C++ host layer and its drivers (the `ex1 / bake-off problems run unchanged through C++
+    # host code` half of the north star): examples/bin/bench_ceed as child processes, after every timed region of this one
+    cxx = None
+    if rank == 0 and world == 1 and not args.no_cxx:
+        torch.cuda.empty_cache()
+        cxx = cxx_drivers(args.problem)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         from mfem_amd.tables import bakeoff_tables
@@ -235,21 +247,78 @@ def main():
                                       f"D1D={D} Q1D={Q}, Cartesian hex mesh {n}^3 per GPU",
                           "elements_per_gpu": ne, "local_dofs_per_gpu": ndofs, "global_dofs": total_dofs,
                           "process_grid": list(pg), "transport": transport,
-                          "numbering": numbering_for(ndofs, p) if world == 1 else "lexicographic",
+                          "numbering": numbering_for(ndofs, p),
                           "element_interior_rows_written_by_element_kernel": int(n_direct)},
                "roofline": roof, "roofline_apply": roof_apply, "graph_replay": replay, "cg": cg, "by_order": by_order, "by_size": by_size,
-               "cpu_baseline": cpu,
+               "cxx_drivers": cxx, "cpu_baseline": cpu,
                "setup_s": setup_s}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
 
-# L-dof numbering of the single-GPU boxes: "interior-last" = vertex/edge/face dofs (lexicographic among themselves), then
-# the element-interior dofs element by element -- the class of numberings the reference gives every H1 space
-# (fem/fespace.cpp), which lets the element kernel write those rows itself (mfem_amd_interior_rows);
-# "lexicographic" = the plain tensor-grid numbering (what the multi-GPU boxes still use).
-NUMBERING = os.environ.get("MFEM_AMD_BENCH_NUMBERING", "interior-last")
+# L-dof numbering and element order of the boxes (every rank's box at N > 1):
+#   "mfem" (default)  the reference's own: Mesh::MakeCartesian3D in its space-filling-curve element order, H1 dofs numbered
+#                     vertex / edge / face / interior (fem/fespace.cpp) -- tables from the C++ host layer
+#                     (mfem_amd/hosttables.py), i.e. what examples/bin/bench_ceed and ex1 run on;
+#   "interior-last"   tensor-grid order of the vertex/edge/face dofs, element-interior dofs last, lexicographic elements;
+#   "lexicographic"   the plain tensor-grid numbering (no reference caller produces it; kept for comparisons).
+NUMBERING = os.environ.get("MFEM_AMD_BENCH_NUMBERING", "mfem")
+
+
+def launch_ranks(n, argv):
+    """One process per GPU through torch.distributed.run, as the driver's own command line does; the JSON line of rank 0 is
+    relayed as the only stdout line.  With fewer than n devices visible (a rehearsal on a one-GPU box) the ranks share the
+    devices and the exchange goes through the host (config.transport says so).  Returns the exit code."""
+    import socket
+    import subprocess
+    import torch
+    env = dict(os.environ)
+    if torch.cuda.device_count() < n:                # (counting devices does not initialise the GPU)
+        env.setdefault("MFEM_AMD_DIST_BACKEND", "gloo")
+        env.setdefault("MFEM_AMD_BENCH_TRANSPORT", "native-tcp")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        sys.stderr.write(r.stdout)
+        return r.returncode or 1
+    print(lines[-1])
+    return 0
+
+
+def cxx_drivers(problem):
+    """examples/bin/bench_ceed (the bake-off Kernel / Problem set-up of tests/benchmarks/bench_ceed.cpp on the C++ host layer)
+    at p = 4, 5, 6, ~1e7 dofs: whole-apply and Jacobi-PCG fractions of the 8 TB/s roofline on SURVEY 8d's bytes."""
+    import subprocess
+    exe = ROOT / "examples" / "bin" / "bench_ceed"
+    if not exe.exists():
+        return {"error": f"{exe} is missing (make -C mfem_amd/host)"}
+    rows = []
+    for q in (4, 5, 6):
+        cmd = [str(exe), "-bp", problem[2:], "-p", str(q), "-n", str(round(216/q)), "-reps", "50", "-mi", "50", "-rtol", "0"]
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        except subprocess.TimeoutExpired:
+            rows.append({"p": q, "error": "timeout"})
+            continue
+        ph = {}
+        for ln in r.stdout.splitlines():
+            if ln.startswith("{"):
+                d = json.loads(ln)
+                ph[d["phase"]] = d
+        if r.returncode != 0 or "kernel" not in ph or "problem" not in ph:
+            rows.append({"p": q, "error": (r.stderr or r.stdout)[-300:]})
+            continue
+        k, pr = ph["kernel"], ph["problem"]
+        rows.append({"p": q, "dofs": k["dofs"], "ms_per_apply": k["ms_per_apply"], "cxx_apply_frac": k["hbm_frac"],
+                     "GDOF/s": k["MDof/s"]*1e-3, "pcg_iterations": pr["iterations"],
+                     "ms_per_iter": pr["solve_s"]/max(1, pr["iterations"])*1e3, "cxx_pcg_frac": pr["hbm_frac"], "setup_s": k["setup_s"]})
+    return {"driver": "examples/bin/bench_ceed -bp %s -p <p> -n <216/p> -reps 50 -mi 50 -rtol 0" % problem[2:], "rows": rows}
 
 
 def kernel_times(bp, x, y, k):
@@ -271,9 +340,9 @@ def kernel_times(bp, x, y, k):
 
 
 def numbering_for(ndofs, p):
-    """interior-last where the library uses it (p >= 4 and y within the Infinity Cache: vector_cg.hip, constrained_mult);
-    elsewhere the plain grid numbering, whose gathers are the more local ones (profiles/r2/direct_rows.txt)"""
-    return NUMBERING if p >= 4 and ndofs*8 <= (256 << 20) else "lexicographic"
+    """one numbering for every row of every table (NUMBERING above); the library decides per case whether the interior
+    rows go direct (vector_cg.hip: constrained_mult) -- the rows report it"""
+    return NUMBERING
 
 
 def spin_count(nbytes):
@@ -464,9 +533,39 @@ def cpu_baseline(problem, p, seconds):
            "host_physical_cores": phys, "host_logical_cpus": logical,
            "sample": f"{reps} L->L applies of the same operator (p={p}, Q1D={Q}) on a {n}^3 mesh, {ndofs} dofs, "
                      f"{el:.1f} s, OpenMP over elements"}
+    # one core on the mesh of BASELINE.md's probe (48/p elements per direction, ~1.2e5 dofs, cache-resident): the figure that
+    # compares with the compiled reference's single-core numbers there (13.1 MDOF/s at BP3 p = 4 in the survey container)
+    nthreads = int(orc.lib.orc_num_threads())
+    try:
+        orc.lib.orc_set_num_threads(1)
+        ns = max(2, 48//p)
+        ps = CartesianProblem(p, ns, ns, ns)
+        Js = np.zeros(9*Q**3*ps.ne)
+        orc.lib.orc_jacobians_3d(2, Q, ps.ne, Bn, Gn, ps.nodes_E, Js)
+        if kind:
+            pas = np.zeros(6*Q**3*ps.ne); orc.lib.orc_diffusion_setup_3d(Q, 1, ps.ne, W, Js, c1, 1, pas)
+        else:
+            ds = np.zeros(Q**3*ps.ne); orc.lib.orc_det_3d(Q, ps.ne, Js, ds)
+            pas = np.zeros(Q**3*ps.ne); orc.lib.orc_mass_setup_3d(Q, ps.ne, W, ds, c1, 1, pas)
+        ops = orc.Operator(kind, D, Q, ps.ne, ps.ndofs, B, G, pas, ps.gather_map, ps.offsets, ps.indices)
+        xs = np.random.default_rng(2).random(ps.ndofs)
+        ops.mult(xs)
+        r1, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 2.0:
+            ops.mult(xs); r1 += 1
+        e1 = time.perf_counter() - t0
+        out["one_core"] = {"MDOF/s": ps.ndofs*r1/e1/1e6, "sample": f"{r1} applies on a {ns}^3 mesh ({ps.ndofs} dofs), one thread, {e1:.1f} s",
+                           "reference_in_survey_container_MDOF/s": {"bp3": [3.2, 7.3, 8.2, 13.1, 14.7, 13.6, 14.7, 11.8],
+                                                                    "bp1": [9.9, 21.5, 31.4, 35.3, 37.2, 38.5, 38.4, 26.1],
+                                                                    "bp5": [7.4, 14.0, 17.0, 17.9, 20.3, 18.7, 17.0, 14.2]}.get(problem, [None]*8)[p - 1]}
+    finally:
+        orc.lib.orc_set_num_threads(nthreads)
     if kind:
-        # the same Jacobi-PCG as the `cg` object (unit source, all-boundary Dirichlet), a fixed number of iterations:
-        # the oracle's apply is threaded, its vector updates and dots are the reference's sequential loops
+        # the same Jacobi-PCG as the `cg` object (unit source, all-boundary Dirichlet), a fixed number of iterations.  The
+        # apply is threaded over elements; the vector updates and dot products are threaded over contiguous blocks, one
+        # per core, partial sums added in block order (what MFEM's -d cpu path does with one MPI rank per core; the sum
+        # order differs from the sequential single-rank reference: a timing leg, not a parity one)
+        orc.lib.orc_set_threaded_vectors(1)
         ess = prob.boundary_dofs().astype(np.int32)
         opc = orc.Operator(kind, D, Q, ne, ndofs, B, G, pa, prob.gather_map, prob.offsets, prob.indices, ess=ess)
         dinv = orc.jacobi_setup(opc.diag(), ess)
@@ -479,8 +578,9 @@ def cpu_baseline(problem, p, seconds):
         t0 = time.perf_counter()
         _, its, _, _ = opc.pcg(b, dinv, 0.0, max_iter=its_cap)
         elc = time.perf_counter() - t0
+        orc.lib.orc_set_threaded_vectors(0)
         out["cg_dofs_iter_per_s"] = ndofs*its/elc
-        out["cg_sample"] = f"{its} Jacobi-PCG iterations on the same mesh, {elc:.2f} s"
+        out["cg_sample"] = f"{its} Jacobi-PCG iterations on the same mesh, {elc:.2f} s, vector updates and dots threaded per core"
     return out
 
 

@@ -18,7 +18,7 @@ static double now() { return std::chrono::duration<double>(std::chrono::steady_c
 
 static int reps = 20, max_it = 2000, seed = 1;
 static double rtol = 1e-12;
-static bool jacobi = true, lex = false, varcoef = false;
+static bool jacobi = true, lex = false, varcoef = false, check = false;
 static const char *mesh_file = "";
 static int ref_levels = 0;
 
@@ -41,6 +41,8 @@ int main(int argc, char *argv[])
    args.AddOption(&device_config, "-d", "--device", "Device configuration string.");
    args.AddOption(&mesh_file, "-m", "--mesh", "Hexahedral mesh file instead of the Cartesian box (curved meshes: BASELINE config 4).");
    args.AddOption(&ref_levels, "-r", "--refine", "Uniform refinement levels of the mesh file.");
+   args.AddOption(&check, "-check", "--property-checks", "-no-check", "--no-property-checks",
+                  "Size-independent properties of the operator in the kernel line: symmetry, action on constants.");
    args.AddOption(&varcoef, "-vc", "--variable-coefficient", "-cc", "--constant-coefficient",
                   "Coefficient 1 + x^2 + y z at the quadrature points instead of 1 (scalar problems).");
    args.Parse();
@@ -102,6 +104,20 @@ static void run_case(int bp, int p, int N)
    if (from_file) { N = 0; }
    // vector spaces: q-data, gather_map and indices once per element; x, y per vdof; offsets per scalar dof
    const double bytes_apply = NE*((mass ? 1 : 6)*Q1*Q1*Q1*8 + 2*D1*D1*D1*4) + 16.0*dofs + 4.0*dofs/VDIM;
+   if (check)
+   {
+      // properties that hold at any size (the known answers stop at ~1e5 dofs): (x, A z) = (z, A x); the diffusion
+      // operator annihilates constants, the mass operator integrates them: (1, M 1) = volume of the unit cube
+      GridFunction z(&fes), w(&fes);
+      z.Randomize(seed + 1);
+      a.Mult(z, w);
+      const double xw = x*w, zy = z*y;
+      z = 1.0;
+      a.Mult(z, w);
+      const double cst = mass ? std::fabs((z*w)/VDIM - 1.0) : w.Norml2()/ynorm;
+      printf("{\"phase\": \"check\", \"bp\": %d, \"p\": %d, \"dofs\": %d, \"sym_err\": %.3e, \"const_err\": %.3e}\n", bp, p, dofs,
+             std::fabs(xw - zy)/std::fabs(xw), cst);
+   }
    printf("{\"phase\": \"kernel\", \"bp\": %d, \"p\": %d, \"N\": %d, \"NE\": %d, \"dofs\": %d, \"norm_Ax\": %.15e, \"ms_per_apply\": %.6f, "
           "\"MDof/s\": %.3f, \"GB/s\": %.1f, \"hbm_frac\": %.4f, \"setup_s\": %.3f}\n", bp, p, N, mesh.GetNE(), dofs, ynorm, t_apply*1e3,
           1e-6*dofs/t_apply, 1e-9*bytes_apply/t_apply, 1e-9*bytes_apply/t_apply/8000.0, t_setup);

@@ -310,6 +310,8 @@ typedef struct mfem_amd_pa_operator
                                 else doubles between the components' pa_data arrays */
    int64_t direct_rows;      /* 0, or what mfem_amd_interior_rows returned for gather_map / offsets: the last direct_rows
                                 L-rows are element-interior dofs, which the element kernel writes itself (scalar spaces) */
+   const int *packed_indices;/* `indices` remapped by mfem_amd_pack_indices: the table of the packed work E-vector that goes
+                                with the direct rows (NULL: no direct rows, the plain two-kernel form) */
 } mfem_amd_pa_operator;
 
 /* Element-interior dofs belong to one element, so their rows of G^T are single entries: when they are the LAST
@@ -323,22 +325,34 @@ typedef struct mfem_amd_pa_operator
 int mfem_amd_interior_rows(int D1D, int64_t ne, int64_t ndofs, const int *gather_map, const int *offsets,
                            int *work, int64_t *direct_rows, void *stream);
 
-/* The element kernel of mfem_amd_pa_apply_L2L alone (mfem_amd_pa_apply_L2E with the element-interior rows stored to
- * y_interior[e*(D1D-2)^3 + lexicographic interior index] instead of to yE; the other entries of yE as always).
- * y_interior = y + ndofs - direct_rows for a space that passed mfem_amd_interior_rows.  For callers that run the
- * two halves of the apply themselves (timing, overlap with an exchange). */
-int mfem_amd_pa_apply_L2E_direct(int kind, int pa_layout, int D1D, int Q1D, int64_t ne,
+/* The packed form of the work E-vector between the two kernels of the apply (fem/bilinearform_ext.cpp:540-558: localY
+ * written by AddMultPA, read by ElementRestriction::MultTranspose, fem/restriction.cpp:152-180).  With the element-interior
+ * rows gone (mfem_amd_interior_rows) the reference's (D,D,D,NE) layout would be written with holes -- every sector of it
+ * still travels -- and read a sector at a time by row blocks that want one class of entries (MFEM numbers vertex, edge,
+ * face dofs class after class).  The packed form keeps each element's NS = D1D^3 - (D1D-2)^3 surviving entries contiguous,
+ * class by class: 8 vertex entries, 12 edges (D1D-2 each), 6 faces ((D1D-2)^2 each).  mfem_amd_pack_indices remaps the nnz
+ * entries of `indices` once (signs kept; element-interior entries, which nothing reads, map to the element's first
+ * entry): rows are summed from the same values in the same order -- bit-identical y.  packed_indices: nnz ints (device). */
+int mfem_amd_pack_indices(int D1D, int64_t nnz, const int *indices, int *packed_indices, void *stream);
+
+/* The element kernel of mfem_amd_pa_apply_L2L alone, for callers that run the two halves of the apply themselves (timing,
+ * overlap with an exchange): mfem_amd_pa_apply_L2E with the element-interior rows stored to
+ * y_interior[e*(D1D-2)^3 + lexicographic interior index] (= y + ndofs - direct_rows for a space that passed
+ * mfem_amd_interior_rows) and everything else to the packed E-vector yE_packed (NE*NS doubles), which
+ * mfem_amd_restrict_scatter then reads over the first ndofs - direct_rows rows through packed_indices. */
+int mfem_amd_pa_apply_L2E_packed(int kind, int pa_layout, int D1D, int Q1D, int64_t ne,
                                  const double *B, const double *G, const double *D,
-                                 const int *gather_map, const double *x, double *yE,
+                                 const int *gather_map, const double *x, double *yE_packed,
                                  double *y_interior, void *stream);
 
 /* PABilinearFormExtension::Mult on L-vectors (fem/bilinearform_ext.cpp:487-564: ElementRestriction::Mult, the
  * integrator's AddMultPA, ElementRestriction::MultTranspose) as two kernels: y = G^T A_E G x.
- * direct_rows: 0 or the value from mfem_amd_interior_rows.  yE: NE*D1D^3 doubles of work space. */
+ * direct_rows: 0 or the value from mfem_amd_interior_rows, then with packed_indices from mfem_amd_pack_indices (NULL
+ * otherwise).  yE: NE*D1D^3 doubles of work space. */
 int mfem_amd_pa_apply_L2L(int kind, int pa_layout, int D1D, int Q1D, int64_t ne, int64_t ndofs,
                           const double *B, const double *G, const double *D, const int *gather_map,
-                          const int *offsets, const int *indices, int64_t direct_rows,
-                          const double *x, double *yE, double *y, void *stream);
+                          const int *offsets, const int *indices, const int *packed_indices,
+                          int64_t direct_rows, const double *x, double *yE, double *y, void *stream);
 
 /* ConstrainedOperator(PABilinearFormExtension)::Mult, DIAG_ONE
  * (linalg/operator.cpp:586-646 over fem/bilinearform_ext.cpp:487-564):

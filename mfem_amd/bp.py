@@ -30,7 +30,14 @@ class BakeoffProblem:
         minute at 1e8 dofs."""
         self.dev = torch.device(device)
         self.part, self.ex, self.layout = part, exchange, layout
-        self.prob = part.prob if part is not None else CartesianProblem(p, n[0], n[1], n[2], transpose=not device_tables)
+        if part is not None:
+            self.prob = part.prob
+        elif numbering == "mfem":
+            # the reference's element order and dof numbering (MakeCartesian3D + H1 space, built by the C++ host layer)
+            from .hosttables import MfemBox
+            self.prob = MfemBox(p, n[0], n[1], n[2], transpose=not device_tables)
+        else:
+            self.prob = CartesianProblem(p, n[0], n[1], n[2], transpose=not device_tables)
         pr = self.prob
         self.kind, self.D, self.Q, self.B, self.G, Bn, Gn, W = bakeoff_tables(problem, p)
         kind, D, Q = self.kind, self.D, self.Q
@@ -57,7 +64,11 @@ class BakeoffProblem:
             # the blocked pa_data layout is addressed per batch of NBZ elements: split on a batch boundary
             nbz = capi.lib.mfem_amd_pa_data_size(kind, 1, Q, 1)//((6 if kind else 1)*Q**3) if layout else 1
             self.e_split = (n_int//nbz)*nbz
-            if 0 < self.e_split and iface.any():
+            ordered = not iface[:n_int].any()          # the partition already lists its interior elements first
+            if 0 < self.e_split and iface.any() and ordered:
+                self._cstream = torch.cuda.Stream(self.dev)
+                self._ev_x, self._ev_ghosts = torch.cuda.Event(), torch.cuda.Event()
+            elif 0 < self.e_split and iface.any():
                 perm = np.concatenate([np.flatnonzero(~iface), np.flatnonzero(iface)])
                 gmap = gmap[perm]
                 nodes_E = np.asarray(nodes_E).reshape(self.ne, -1)[perm].reshape(-1)
@@ -125,12 +136,18 @@ class BakeoffProblem:
                                   _p(self.marker), _p(self.yE), self.vdim, 1 if self.vdim else 0, 0)
         # element-interior rows the element kernel may write itself (include/mfem_amd.h: mfem_amd_interior_rows)
         self.direct = 0
-        if not self.vdim and part is None and os.environ.get("MFEM_AMD_DIRECT_ROWS", "1") != "0":
+        if not self.vdim and os.environ.get("MFEM_AMD_DIRECT_ROWS", "1") != "0":
             work = torch.zeros(1, dtype=torch.int32, device=self.dev)
             dr = C.c_int64(0)
             capi.call("mfem_amd_interior_rows", D, self.ne, self.nscalar, _p(self.gm), _p(self.off), _p(work), C.byref(dr), self.stream)
             self.direct = int(dr.value)
         self.op.direct_rows = self.direct
+        # with them, the E-vector in its packed form: `indices` remapped once (include/mfem_amd.h: mfem_amd_pack_indices)
+        self.pind = None
+        if self.direct:
+            self.pind = torch.empty_like(self.ind)
+            capi.call("mfem_amd_pack_indices", D, self.ind.numel(), _p(self.ind), _p(self.pind), self.stream)
+            self.op.packed_indices = self.pind.data_ptr()
         self.ghost = None
         if part is not None:
             g = np.asarray(part.ext_ldof, np.int64)
@@ -157,10 +174,15 @@ class BakeoffProblem:
         e1 = self.ne if e1 is None else e1
         if e1 <= e0:
             return
-        if y is not None and self.direct_active() and e0 == 0 and e1 == self.ne:
-            yi = C.c_void_p(y.data_ptr() + 8*(self.nscalar - self.direct))
-            capi.call("mfem_amd_pa_apply_L2E_direct", self.kind, self.layout, self.D, self.Q, self.ne, self.B, self.G, _p(self.pa),
-                      _p(self.gm), _p(x), _p(self.yE), yi, self.stream)
+        if y is not None and self.direct_active():
+            # interior rows straight to y, everything else to the packed E-vector (mfem_amd_pa_apply_L2E_packed)
+            D3, ni = self.D**3, (self.D - 2)**3
+            nc = 6 if self.kind else 1
+            pa_off = capi.lib.mfem_amd_pa_data_size(self.kind, 1, self.Q, e0) if self.layout else e0*nc*self.Q**3
+            capi.call("mfem_amd_pa_apply_L2E_packed", self.kind, self.layout, self.D, self.Q, e1 - e0, self.B, self.G,
+                      C.c_void_p(self.pa.data_ptr() + 8*pa_off), C.c_void_p(self.gm.data_ptr() + 4*e0*D3), _p(x),
+                      C.c_void_p(self.yE.data_ptr() + 8*e0*(D3 - ni)),
+                      C.c_void_p(y.data_ptr() + 8*(self.nscalar - self.direct + e0*ni)), self.stream)
             return
         D3, vd = self.D**3, max(1, self.vdim)
         nc = 6 if self.kind else 1
@@ -181,7 +203,8 @@ class BakeoffProblem:
                       _p(self.yE), _p(y), 0, 0, self.stream)
             return
         rows = self.ndofs - self.direct if self.direct_active() else self.ndofs        # as mult() does
-        capi.call("mfem_amd_restrict_scatter", rows, _p(self.off), _p(self.ind), _p(self.yE), _p(y), 0, 0, self.stream)
+        ind = self.pind if self.direct_active() else self.ind
+        capi.call("mfem_amd_restrict_scatter", rows, _p(self.off), _p(ind), _p(self.yE), _p(y), 0, 0, self.stream)
 
     def mult(self, x, y):
         """y = A x; in parallel x's ghost entries are refreshed first and y ends with owners
@@ -195,19 +218,20 @@ class BakeoffProblem:
                 self._cstream.wait_event(self._ev_x)
                 self.ex.forward(x.data_ptr(), C.c_void_p(self._cstream.cuda_stream))
                 self._ev_ghosts.record(self._cstream)
-            self.l2e(x, 0, self.e_split)
+            self.l2e(x, 0, self.e_split, y=y)
             cur.wait_event(self._ev_ghosts)
-            self.l2e(x, self.e_split, self.ne)
+            self.l2e(x, self.e_split, self.ne, y=y)
             self.e2l(y)
             self.ex.reverse(y.data_ptr(), self.stream)
             return
         if self.ex is None and not self.vdim:
             capi.call("mfem_amd_pa_apply_L2L", self.kind, self.layout, self.D, self.Q, self.ne, self.nscalar, self.B, self.G,
-                      _p(self.pa), _p(self.gm), _p(self.off), _p(self.ind), self.direct, _p(x), _p(self.yE), _p(y), self.stream)
+                      _p(self.pa), _p(self.gm), _p(self.off), _p(self.ind), _p(self.pind), self.direct, _p(x), _p(self.yE), _p(y),
+                      self.stream)
             return
         if self.ex is not None:
             self.ex.forward(x.data_ptr(), self.stream)
-        self.l2e(x)
+        self.l2e(x, y=y)
         self.e2l(y)
         if self.ex is not None:
             self.ex.reverse(y.data_ptr(), self.stream)

@@ -33,7 +33,8 @@ class PaOperator(C.Structure):
                 ("B", vp), ("G", vp), ("pa_data", vp), ("gather_map", vp),
                 ("masked_gather_map", vp), ("offsets", vp), ("indices", vp),
                 ("ness", i64), ("ess", vp), ("ess_marker", vp), ("yE", vp),
-                ("vdim", cint), ("byvdim", cint), ("pa_comp_stride", i64), ("direct_rows", i64)]
+                ("vdim", cint), ("byvdim", cint), ("pa_comp_stride", i64), ("direct_rows", i64),
+                ("packed_indices", vp)]
 
 
 AR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
@@ -92,8 +93,9 @@ _SIGS = {
     "mfem_amd_jacobi_apply": (cint, [i64, vp, vp, vp, vp]),
     "mfem_amd_pa_constrained_mult": (cint, [C.POINTER(PaOperator), vp, vp, vp]),
     "mfem_amd_interior_rows": (cint, [cint, i64, i64, vp, vp, vp, C.POINTER(i64), vp]),
-    "mfem_amd_pa_apply_L2E_direct": (cint, [cint, cint, cint, cint, i64, _hd, _hd, vp, vp, vp, vp, vp, vp]),
-    "mfem_amd_pa_apply_L2L": (cint, [cint, cint, cint, cint, i64, i64, _hd, _hd, vp, vp, vp, vp, i64, vp, vp, vp, vp]),
+    "mfem_amd_pa_apply_L2L": (cint, [cint, cint, cint, cint, i64, i64, _hd, _hd, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]),
+    "mfem_amd_pack_indices": (cint, [cint, i64, vp, vp, vp]),
+    "mfem_amd_pa_apply_L2E_packed": (cint, [cint, cint, cint, cint, i64, _hd, _hd, vp, vp, vp, vp, vp, vp]),
     "mfem_amd_pcg_workspace_bytes": (i64, [i64, cint]),
     "mfem_amd_shared_pack": (cint, [i64, vp, vp, vp, vp]),
     "mfem_amd_shared_unpack": (cint, [i64, vp, vp, vp, vp]),

@@ -146,8 +146,42 @@ struct VecArgs
                                   // vector diffusion allocates dim*dim = 9 planes per block and fills 6
    double *ydirect;               // scalar gather kernels, optional: the L-vector rows of the element-interior dofs, element e's
                                   // (D-2)^3 rows at ydirect + e*(D-2)^3 in lexicographic order -- written here instead of
-                                  // to the E-vector (mfem_amd_interior_rows)
+                                  // to the E-vector (mfem_amd_interior_rows); the E-vector is then written in the packed
+                                  // form below (packed_pos)
 };
+
+// Packed E-vector (used together with the direct interior rows).  Once the element-interior entries go straight to the
+// L-vector, the reference's (D,D,D,NE) E-vector is written with holes -- runs of D-2 missing doubles in every inner row --
+// so every 32/64-B sector of it still travels to memory and back, and an L-row block of the transpose-gather (MFEM numbers
+// vertex, edge, face dofs class after class) finds the entries it wants one or two to a 128-B line.  The packed form stores
+// the NS = D^3 - (D-2)^3 surviving entries of an element contiguously and class by class -- 8 vertex entries, then the 12
+// edges (D-2 each), then the 6 faces ((D-2)^2 each) -- at e*NS + packed_pos(dz,dy,dx); the transpose-gather reads it
+// through `indices` remapped once at set-up (mfem_amd_pack_indices): same values, same order of additions, same bits.
+// Order inside a class: every row (dz,dy) of the element kernel's store phase owns one contiguous run of D-2 entries (an
+// x-edge, a row of a z- or y-face) plus its two end entries.  Returns -1 for an element-interior entry.
+__host__ __device__ inline int packed_pos(const int D, const int dz, const int dy, const int dx)
+{
+   const int DI = D - 2, E0 = 8, F0 = 8 + 12*DI;
+   const bool nz = dz >= 1 && dz <= DI, ny = dy >= 1 && dy <= DI, nx = dx >= 1 && dx <= DI;
+   const int bz = dz ? 1 : 0, by = dy ? 1 : 0, bx = dx ? 1 : 0;       // side, where the coordinate is on the boundary
+   const int iz = dz - 1, iy = dy - 1, ix = dx - 1;
+   const int nin = (nz ? 1 : 0) + (ny ? 1 : 0) + (nx ? 1 : 0);
+   if (nin == 0) { return bz*4 + by*2 + bx; }
+   if (nin == 1)
+   {
+      if (nx) { return E0 + (bz*2 + by)*DI + ix; }
+      if (ny) { return E0 + 4*DI + (bz*2 + bx)*DI + iy; }
+      return E0 + 8*DI + (by*2 + bx)*DI + iz;
+   }
+   if (nin == 2)
+   {
+      if (!nz) { return F0 + (bz*DI + iy)*DI + ix; }
+      if (!ny) { return F0 + 2*DI*DI + (by*DI + iz)*DI + ix; }
+      return F0 + 4*DI*DI + (bx*DI + iz)*DI + iy;
+   }
+   return -1;
+}
+__host__ __device__ constexpr int packed_size(const int D) { return D*D*D - (D - 2)*(D - 2)*(D - 2); }
 
 // Workgroup sum for blockDim.x == 256 (4 waves); result valid in thread 0.
 // Fixed tree: lanes by shuffle, then waves 0..3 added in order.

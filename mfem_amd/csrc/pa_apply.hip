@@ -734,22 +734,42 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
                }
                double *ye = yE + (VEC ? e*va.vd + comp : e)*D3 + t2*D;
                // rows of element-interior dofs belong to this element alone: their sums ARE these values, so they
-               // go straight to the L-vector and never through the E-vector (uniform branch on a kernel argument)
+               // go straight to the L-vector and never through the E-vector (uniform branch on a kernel argument);
+               // what is left of the element goes to the packed E-vector (common.h: packed_pos): this row's two end
+               // entries and its run of D-2 middle entries -- an x-edge, a row of a z- or y-face, or (inner rows)
+               // the interior run
                if (DIRECT && va.ydirect)
                {
                   // One store per value, its address chosen per lane by mask arithmetic: the rows of one wave differ in
                   // kind, and a branch would issue both forms of the row one after the other.  (Not `c ? p : q` on the
                   // pointers: hipcc 7.2 turns that back into exec-masked blocks and sinks one of the moves out of its
                   // block -- lanes of dy = 0 then stored through their neighbour row's address.)
-                  constexpr int DI = D - 2;
-                  const bool inner = t2 >= D && t2 < D*(D - 1) && t2 % D >= 1 && t2 % D <= D - 2;
-                  const uint64_t pe = reinterpret_cast<uint64_t>(ye);
-                  const uint64_t pd = reinterpret_cast<uint64_t>(va.ydirect + e*(DI*DI*DI) + ((t2/D - 1)*DI + (t2 % D - 1))*DI - 1);
-                  const uint64_t pin = pe ^ ((pe ^ pd) & (uint64_t)(-(int64_t)inner));
+                  constexpr int DI = D - 2, E0 = 8, F0 = 8 + 12*DI;
+                  // (opaque copies of the row and element indices: everything derived from them is computed here, after
+                  // the z loop, instead of being hoisted above it and held in registers through the kernel's tightest
+                  // phase; the positions are those of packed_pos, written as selects so that no lane branches)
+                  int row, ez;
+                  asm volatile("v_mov_b32 %0, %1" : "=v"(row) : "v"(t2));
+                  asm volatile("v_mov_b32 %0, %1" : "=v"(ez) : "v"(tz));
+                  const int64_t eo = bt*NBZ + ez;
+                  const int rz = row/D, ry = row % D, iz = rz - 1, iy = ry - 1;
+                  const int bz = rz ? 1 : 0, by = ry ? 1 : 0;                      // side, where the row is on the boundary
+                  const int mz = -(int)(rz >= 1 && rz <= DI), my = -(int)(ry >= 1 && ry <= DI);   // all ones: inner in z / y
+                  auto sel = [](const int m, const int a, const int b) { return b ^ ((a ^ b) & m); };   // m ? a : b
+                  // first entry (dx = 0), distance to the last (dx = D-1), first of the D-2 middle entries
+                  const int p0 = sel(mz, sel(my, F0 + 4*DI*DI + iz*DI + iy, E0 + 8*DI + by*2*DI + iz),
+                                         sel(my, E0 + 4*DI + bz*2*DI + iy, bz*4 + by*2));
+                  const int dl = sel(mz, sel(my, DI*DI, DI), sel(my, DI, 1));
+                  const int pm = sel(mz, sel(my, (iz*DI + iy)*DI, F0 + 2*DI*DI + (by*DI + iz)*DI),
+                                         sel(my, F0 + (bz*DI + iy)*DI, E0 + (bz*2 + by)*DI));
+                  const uint64_t pb = reinterpret_cast<uint64_t>(yE + eo*packed_size(D));
+                  const uint64_t pd = reinterpret_cast<uint64_t>(va.ydirect + eo*(DI*DI*DI));
+                  const uint64_t a0 = pb + 8u*(unsigned)p0;
+                  const uint64_t am = (pb ^ ((pb ^ pd) & (uint64_t)(int64_t)(mz & my))) + 8u*(unsigned)pm;
 #pragma unroll
                   for (int dx = 0; dx < D; dx++)
                   {
-                     *reinterpret_cast<gdouble*>(((dx >= 1 && dx <= DI) ? pin : pe) + 8u*dx) = yv[dx];
+                     *reinterpret_cast<gdouble*>(dx == 0 ? a0 : (dx == D - 1 ? a0 + 8u*(unsigned)dl : am + 8u*(dx - 1))) = yv[dx];
                   }
                }
                else if (D % 2 == 0)
@@ -795,7 +815,8 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
                {
                   constexpr int DI = D - 2;
                   const bool inner = a >= 1 && a <= DI && b >= 1 && b <= DI && dz >= 1 && dz <= DI;
-                  const uint64_t pe = reinterpret_cast<uint64_t>(ye + dz*D*D);
+                  const int pp = packed_pos(D, dz, b, a);
+                  const uint64_t pe = reinterpret_cast<uint64_t>(yE + e*packed_size(D) + (pp < 0 ? 0 : pp));
                   const uint64_t pd = reinterpret_cast<uint64_t>(va.ydirect + e*(DI*DI*DI) + ((dz - 1)*DI + (b - 1))*DI + (a - 1));
                   *reinterpret_cast<gdouble*>(pe ^ ((pe ^ pd) & (uint64_t)(-(int64_t)inner))) = y;     // (mask, not ?: -- see the RB form)
                }
@@ -979,6 +1000,7 @@ k_pa_apply_generic(const int D, const int Q, const int64_t ne, const BasisT<MAX_
       {
          va.ydirect[(int64_t)blockIdx.x*(DI*DI*DI) + ((dz - 1)*DI + (dy - 1))*DI + (dx - 1)] = y;
       }
+      else if (GATHER && !ACCUM && va.ydirect) { yE[e*packed_size(D) + packed_pos(D, dz, dy, dx)] = y; }
       else if (ACCUM) { yE[eblk*D3 + i] += y; }
       else { yE[eblk*D3 + i] = y; }
    }
@@ -1383,15 +1405,15 @@ extern "C" int mfem_amd_pa_apply_L2E(int kind, int pa_layout, int D1D, int Q1D, 
 }
 
 
-extern "C" int mfem_amd_pa_apply_L2E_direct(int kind, int pa_layout, int D1D, int Q1D, int64_t ne,
+extern "C" int mfem_amd_pa_apply_L2E_packed(int kind, int pa_layout, int D1D, int Q1D, int64_t ne,
                                             const double *B, const double *G, const double *D,
-                                            const int *gather_map, const double *x, double *yE,
+                                            const int *gather_map, const double *x, double *yE_packed,
                                             double *y_interior, void *stream)
 {
-   MFA_REQUIRE(kind == 0 || kind == 1, "pa_apply_L2E_direct: kind must be 0 (mass) or 1 (diffusion)");
-   MFA_REQUIRE(pa_layout == 0 || pa_layout == 1, "pa_apply_L2E_direct: pa_layout must be 0 (MFEM) or 1 (blocked)");
-   MFA_REQUIRE(D1D >= 3 && y_interior, "pa_apply_L2E_direct: needs D1D >= 3 and the interior rows of y");
-   return pa_apply_L2E(kind, pa_layout, D1D, Q1D, ne, B, G, D, gather_map, x, yE, as_stream(stream), y_interior);
+   MFA_REQUIRE(kind == 0 || kind == 1, "pa_apply_L2E_packed: kind must be 0 (mass) or 1 (diffusion)");
+   MFA_REQUIRE(pa_layout == 0 || pa_layout == 1, "pa_apply_L2E_packed: pa_layout must be 0 (MFEM) or 1 (blocked)");
+   MFA_REQUIRE(D1D >= 3 && y_interior, "pa_apply_L2E_packed: needs D1D >= 3 and the interior rows of y");
+   return pa_apply_L2E(kind, pa_layout, D1D, Q1D, ne, B, G, D, gather_map, x, yE_packed, as_stream(stream), y_interior);
 }
 
 extern "C" int mfem_amd_pa_apply_L2E_vdim(int kind, int pa_layout, int D1D, int Q1D, int64_t ne,

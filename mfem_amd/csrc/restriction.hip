@@ -263,13 +263,18 @@ k_scatter(const int64_t ndofs, const int *__restrict__ offsets,
    if (skip && *skip) { return; }
    double prod = 0.0;
    // rows ndofs .. ndofs + ndirect - 1 were written by the element kernel (element-interior dofs): nothing to sum,
-   // only their part of (w, y), streamed in a fixed thread order
-   if (DOT && ndirect > 0)
+   // only their part of (w, y), streamed in a fixed thread order -- and the constraint: an element-interior dof can
+   // be in the essential list too (a pinned dof, dofs of an element attribute), and its row then takes x (marker 1) or
+   // 0 (marker 2) like any other row (ConstrainedOperator, linalg/operator.cpp:624-629)
+   if ((DOT || marker) && ndirect > 0)
    {
-      const double *yd = y;             // (read-only here; the rows this kernel writes are below ndofs)
       for (int64_t i = ndofs + (int64_t)blockIdx.x*256 + threadIdx.x; i < ndofs + ndirect; i += (int64_t)gridDim.x*256)
       {
-         prod += w[i]*yd[i];
+         const unsigned char m = marker ? marker[i] : (unsigned char)0;
+         double r = 0.0;
+         if (m) { r = (m == 1) ? xin[i] : 0.0; y[i] = r; }
+         else if (DOT) { r = y[i]; }
+         if (DOT) { prod += w[i]*r; }
       }
    }
    // Wave-uniform choice by the table's own average row length nnz/ndofs (profiles/r1/e2l_rows_probe.txt,
@@ -672,7 +677,7 @@ int scatter_dot(int64_t ndofs, const int *offsets, const int *indices, const dou
    else
    {
       k_scatter<0, false><<<dim3(nblocks), dim3(256), 0, s>>>(ndofs, offsets, indices, xE, y,
-                                                            marker, xin, nullptr, nullptr, skip, scatter_flags(), 0);
+                                                            marker, xin, nullptr, nullptr, skip, scatter_flags(), marker ? ndirect : 0);
    }
    MFA_CHECK_LAUNCH("k_scatter");
    return 0;
@@ -809,6 +814,34 @@ extern "C" int mfem_amd_interior_rows(int D1D, int64_t ne, int64_t ndofs, const 
    if (int rc = check_hip(hipMemcpyAsync(&bad, work, sizeof(int), hipMemcpyDeviceToHost, s), "hipMemcpyAsync")) { return rc; }
    if (int rc = check_hip(hipStreamSynchronize(s), "hipStreamSynchronize")) { return rc; }
    if (!bad) { *direct_rows = ne*ni; }
+   return 0;
+}
+
+// `indices` of the transpose-gather for the packed E-vector (common.h: packed_pos): entry e*D^3 + i -> e*NS + packed_pos(i),
+// signs kept (-1 - idx).  Element-interior entries (rows the element kernel writes itself) have no place in the packed
+// form; they map to the element's first entry and are never read.
+__global__ void __launch_bounds__(256)
+k_pack_indices(const int D, const int64_t nnz, const int *__restrict__ indices, int *__restrict__ packed)
+{
+   const int D3 = D*D*D, NS = packed_size(D);
+   for (int64_t k = (int64_t)blockIdx.x*256 + threadIdx.x; k < nnz; k += (int64_t)gridDim.x*256)
+   {
+      const int idx = indices[k];
+      const int j = idx >= 0 ? idx : -1 - idx;
+      const int e = j/D3, i = j - e*D3;
+      const int pos = packed_pos(D, i/(D*D), (i/D) % D, i % D);
+      const int out = e*NS + (pos < 0 ? 0 : pos);
+      packed[k] = idx >= 0 ? out : -1 - out;
+   }
+}
+
+extern "C" int mfem_amd_pack_indices(int D1D, int64_t nnz, const int *indices, int *packed_indices, void *stream)
+{
+   if (nnz == 0) { return 0; }
+   MFA_REQUIRE(D1D >= 3 && D1D <= MAX_D1D && nnz > 0 && indices && packed_indices, "pack_indices: bad arguments (D1D >= 3)");
+   const int64_t nb = (nnz + 255)/256;
+   k_pack_indices<<<dim3((unsigned)(nb < 65536 ? nb : 65536)), dim3(256), 0, as_stream(stream)>>>(D1D, nnz, indices, packed_indices);
+   MFA_CHECK_LAUNCH("k_pack_indices");
    return 0;
 }
 

@@ -128,6 +128,7 @@ struct PcgState
    double rel_tol, abs_tol;
    int hist_n;      // entries of the (B r, r) history written so far
    int k;           // k_pcg_beta_scalars launches so far (no-op launches after the end included)
+   int upd;         // value of k at the last launch that followed a kernel A that ran: kernel B owes x its update
 };
 
 // den = (d, A d) after the first/each operator application (linalg/solvers.cpp:931-949, 1010-1025);
@@ -175,7 +176,7 @@ k_pcg_init_scalars(const int nb, const double *__restrict__ partials, PcgState *
    {
       st->nom = st->nom0 = st->betanom = nom;
       st->iter = 0; st->converged = 0; st->done = 0;
-      st->hist_n = 1; st->k = 0;
+      st->hist_n = 1; st->k = 0; st->upd = -1;
       if (hist) { hist[0] = nom; }
       const double r0 = fmax(nom*st->rel_tol*st->rel_tol, st->abs_tol*st->abs_tol);
       st->r0 = r0;
@@ -201,10 +202,13 @@ __device__ __forceinline__ void pcg_beta_step(PcgState *st, const double betanom
 {
    const int i = st->iter + 1;        // the iteration whose update just ran
    st->betanom = betanom;
+   st->upd = st->k;
+   // a negative or NaN (B r, r) ends the solve BEFORE the reference monitors it (linalg/solvers.cpp:969-978: the break
+   // precedes the print / Monitor call), so it is not part of the history
+   if (!(betanom >= 0.0)) { st->iter = i; st->done = 1; return; }
    st->hist_n = i + 1;
    if (hist) { hist[i] = betanom; }
-   if (!(betanom >= 0.0)) { st->iter = i; st->done = 1; }
-   else if (betanom <= st->r0) { st->iter = i; st->converged = 1; st->done = 1; }
+   if (betanom <= st->r0) { st->iter = i; st->converged = 1; st->done = 1; }
    else if (i + 1 > st->max_iter) { st->iter = st->max_iter; st->done = 1; }
    else { st->iter = i; st->beta = betanom/st->nom; }
 }
@@ -259,7 +263,7 @@ __global__ void __launch_bounds__(256)
 k_pcg_dir(const int64_t n, const PcgState *__restrict__ st, const double *__restrict__ z,
           double *__restrict__ d, double *__restrict__ x)
 {
-   const bool xup = st->k == st->hist_n - 1;      // kernel A of this iteration ran (its (B r, r) is the last recorded)
+   const bool xup = st->k == st->upd;             // kernel A of this iteration ran (no-op launches after the end: k moved on)
    if (!xup) { return; }
    const double alpha = st->alpha, beta = st->beta;
    if (st->done)
@@ -461,8 +465,10 @@ static int constrained_mult(const mfem_amd_pa_operator *op, const mfem_amd_comm 
    {
       if (int rc = comm->forward(comm->ctx, x, (void*)s)) { set_error("comm forward exchange failed (%d)", rc); return rc; }
    }
-   // NOTE: the element kernel is not gated by `skip`: after convergence it only rewrites
-   // the work E-vector, and the gated transpose-gather leaves y untouched.
+   // NOTE: the element kernel is not gated by `skip`: launched after convergence it rewrites the work E-vector and, with
+   // direct rows, the element-interior rows y[ndofs - direct_rows, ndofs) -- the gated transpose-gather leaves the
+   // rest of y untouched.  `skip` is only passed by the solver, whose y is its work vector z (dead after the end: x has
+   // had its last update); a caller that wants y preserved after `skip` must not enable direct rows.
    // Element-interior rows (the last direct_rows ones, mfem_amd_interior_rows) are written by the element kernel itself and
    // the transpose-gather sums the rows before them -- where that pays (profiles/r2/direct_rows.txt): the direct stores
    // are short runs (D-2 doubles) that complete each other's cache lines only while y stays in the 256 MiB Infinity
@@ -474,13 +480,14 @@ static int constrained_mult(const mfem_amd_pa_operator *op, const mfem_amd_comm 
    const int policy = pol ? atoi(pol) : 1;
    const bool pays = policy == 2 || (policy == 1 && op->D1D >= 5 && op->ndofs*(int64_t)sizeof(double) <= ((int64_t)256 << 20) &&
                                      (!w || pcg_nt(op->ndofs)));
-   const int64_t nd = (op->direct_rows > 0 && op->kind != 2 && pays) ? op->direct_rows : 0;
+   // (the E-vector is then the packed one, read through op->packed_indices: no direct rows without that table)
+   const int64_t nd = (op->direct_rows > 0 && op->packed_indices && op->kind != 2 && pays) ? op->direct_rows : 0;
    MFA_REQUIRE(nd >= 0 && nd <= op->ndofs, "pa operator: direct_rows out of range");
    const int64_t nrows = op->ndofs - nd;
    if (nd && !w) { nb = (int)((nrows + 1023)/1024 > 0 ? (nrows + 1023)/1024 : 1); }
    if (int rc = pa_apply_L2E(op->kind, op->pa_layout, op->D1D, op->Q1D, op->ne, op->B, op->G, op->pa_data, gm, x, op->yE, s,
                              nd ? y + nrows : nullptr)) { return rc; }
-   if (int rc = scatter_dot(nrows, op->offsets, op->indices, op->yE, y, ess ? op->ess_marker : nullptr,
+   if (int rc = scatter_dot(nrows, op->offsets, nd ? op->packed_indices : op->indices, op->yE, y, ess ? op->ess_marker : nullptr,
                             x, w, partials, nb, skip, s, nd)) { return rc; }
    if (comm)
    {
@@ -502,8 +509,8 @@ extern "C" int mfem_amd_pa_constrained_mult(const mfem_amd_pa_operator *op, cons
 
 extern "C" int mfem_amd_pa_apply_L2L(int kind, int pa_layout, int D1D, int Q1D, int64_t ne, int64_t ndofs,
                                      const double *B, const double *G, const double *D, const int *gather_map,
-                                     const int *offsets, const int *indices, int64_t direct_rows,
-                                     const double *x, double *yE, double *y, void *stream)
+                                     const int *offsets, const int *indices, const int *packed_indices,
+                                     int64_t direct_rows, const double *x, double *yE, double *y, void *stream)
 {
    MFA_REQUIRE(kind == 0 || kind == 1, "pa_apply_L2L: kind must be 0 (mass) or 1 (diffusion)");
    MFA_REQUIRE(pa_layout == 0 || pa_layout == 1, "pa_apply_L2L: pa_layout must be 0 (MFEM) or 1 (blocked)");
@@ -511,11 +518,12 @@ extern "C" int mfem_amd_pa_apply_L2L(int kind, int pa_layout, int D1D, int Q1D, 
    MFA_REQUIRE(x && y && yE && x != y && offsets && indices && gather_map, "pa_apply_L2L: bad arguments");
    MFA_REQUIRE(direct_rows == 0 || (D1D >= 3 && direct_rows == ne*(int64_t)(D1D - 2)*(D1D - 2)*(D1D - 2)),
                "pa_apply_L2L: direct_rows must be 0 or NE*(D1D-2)^3 (mfem_amd_interior_rows)");
+   MFA_REQUIRE(direct_rows == 0 || packed_indices, "pa_apply_L2L: direct_rows needs packed_indices (mfem_amd_pack_indices)");
    if (ndofs == 0) { return 0; }
    mfem_amd_pa_operator op = {};
    op.kind = kind; op.pa_layout = pa_layout; op.D1D = D1D; op.Q1D = Q1D; op.ne = ne; op.ndofs = ndofs;
    op.B = B; op.G = G; op.pa_data = D; op.gather_map = gather_map; op.offsets = offsets; op.indices = indices;
-   op.yE = yE; op.direct_rows = direct_rows;
+   op.yE = yE; op.direct_rows = direct_rows; op.packed_indices = packed_indices;
    const int64_t nb = (ndofs + 1023)/1024;
    return constrained_mult(&op, nullptr, const_cast<double*>(x), y, nullptr, nullptr, (int)nb, nullptr, as_stream(stream));
 }

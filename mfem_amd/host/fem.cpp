@@ -283,6 +283,17 @@ ElementRestriction::ElementRestriction(const FiniteElementSpace &f, ElementDofOr
       direct_rows = ok ? (long long)ne*NI : 0;
    }
 }
+const Array<int> &ElementRestriction::PackedIndices() const
+{
+   if (direct_rows > 0 && vdim == 1 && packed_indices.Size() == 0)
+   {
+      int D = 2;
+      while (D*D*D < dof) { ++D; }
+      packed_indices.SetSize(ne*dof);
+      MFEM_AMD_CALL(mfem_amd_pack_indices(D, (int64_t)ne*dof, indices.Read(), packed_indices.Write(), nullptr));
+   }
+   return packed_indices;
+}
 void ElementRestriction::Mult(const Vector &x, Vector &y) const
 {
    MFEM_VERIFY(x.Size() == Width(), "ElementRestriction::Mult: wrong input size");
@@ -576,7 +587,7 @@ void BilinearFormIntegrator::SetupPA(const FiniteElementSpace &fes, int kind_, C
    // symmetric = (coeff_dim != dims*dims), fem/integ/bilininteg_diffusion_pa.cpp:135-137
    symmetric = coeffDim != 9;
    pa_layout = (symmetric && mfem_amd_has_specialization(kind, dofs1D, quad1D)) ? 1 : 0;
-   pa_data.SetSize((int)mfem_amd_pa_data_size(OperatorKind(), pa_layout, quad1D, ne));
+   pa_data.SetSize(mfem_amd_pa_data_size(OperatorKind(), pa_layout, quad1D, ne));     // 64-bit: 2.2e9 doubles at BP3 p = 4, 1e8 dofs
    if (pa_layout) { pa_data.Write(); pa_data = 0.0; }     // padding of the last batch must be finite
    MFEM_AMD_CALL(mfem_amd_pa_setup_from_nodes_3d(kind, g.Dn, quad1D, coeffDim, ne, g.Bn.data(), g.Gn.data(), ir.GetWeights().Read(),
                                                  g.nodesE.Read(), C.Read(), const_c, pa_layout,
@@ -599,12 +610,11 @@ void BilinearFormIntegrator::SetupPAComponents(const FiniteElementSpace &fes, in
    symmetric = true;
    pa_layout = mfem_amd_has_specialization(kind, dofs1D, quad1D) ? 1 : 0;
    const int64_t blk = mfem_amd_pa_data_size(kind, pa_layout, quad1D, ne);
-   MFEM_VERIFY(blk*vdim < (int64_t)2147483647, "mfem_amd: per-component pa_data too large for one Vector");
-   pa_data.SetSize((int)(blk*vdim));
+   pa_data.SetSize(blk*vdim);
    if (pa_layout) { pa_data.Write(); pa_data = 0.0; }     // padding of the last batch must be finite
    const int64_t npts = const_c ? 1 : (int64_t)ir.GetNPoints()*ne;
-   Vector Cc((int)npts), one_comp;
-   if (!pa_layout) { one_comp.SetSize((int)blk); }
+   Vector Cc(npts), one_comp;
+   if (!pa_layout) { one_comp.SetSize(blk); }
    const real_t *c = C.HostRead();
    const int64_t eblk = blk/ne;                            // doubles per element (MFEM layout)
    for (int k = 0; k < vdim; k++)
@@ -631,7 +641,7 @@ const Vector &BilinearFormIntegrator::MFEMLayoutData() const
    if (pa_layout == 0) { return pa_data; }
    if (pa_data_mfem.Size() == 0)
    {
-      pa_data_mfem.SetSize((int)mfem_amd_pa_data_size(kind, 0, quad1D, ne));
+      pa_data_mfem.SetSize(mfem_amd_pa_data_size(kind, 0, quad1D, ne));
       MFEM_AMD_CALL(mfem_amd_pa_data_from_blocked(kind, quad1D, ne, pa_data.Read(), pa_data_mfem.Write(), nullptr));
    }
    return pa_data_mfem;
@@ -761,11 +771,12 @@ void PABilinearFormExtension::Mult(const Vector &x, Vector &y) const
    {
       // both halves in one call: the element-interior rows (the native numbering puts them last) go from the element
       // kernel straight to y, the transpose sums the rows before them (include/mfem_amd.h: mfem_amd_interior_rows)
+      const Array<int> &pk = elem_restrict->PackedIndices();
       MFEM_AMD_CALL(mfem_amd_pa_apply_L2L(bfi->OperatorKind(), bfi->pa_layout, bfi->dofs1D, bfi->quad1D, bfi->ne, fes->GetNDofs(),
                                           bfi->maps->B.HostRead(), bfi->maps->G.HostRead(), bfi->pa_data.Read(),
                                           elem_restrict->GatherMap().Read(), elem_restrict->Offsets().Read(),
-                                          elem_restrict->Indices().Read(), elem_restrict->DirectRows(), x.Read(),
-                                          localY.Write(), y.Write(), nullptr));
+                                          elem_restrict->Indices().Read(), pk.Size() ? pk.Read() : nullptr,
+                                          pk.Size() ? elem_restrict->DirectRows() : 0, x.Read(), localY.Write(), y.Write(), nullptr));
       return;
    }
    else if (const BilinearFormIntegrator *bfi = SingleIntegrator())
@@ -841,7 +852,7 @@ void PABilinearFormExtension::AssembleDiagonal(Vector &diag) const
          {
             // MFEM layout: pull component c out of the interleaved (Q^3, NC, vdim, NE) array
             const int64_t eblk = bfi->pa_comp_stride;
-            Vector comp((int)(eblk*bfi->ne));
+            Vector comp(eblk*bfi->ne);
             internal::CopyRowsOnDevice(comp.Write(), sizeof(real_t)*eblk, bfi->pa_data.Read() + eblk*c, sizeof(real_t)*eblk*vd,
                                        sizeof(real_t)*eblk, (size_t)bfi->ne);
             scalar_diagonal(comp.Read());
@@ -953,6 +964,7 @@ bool PABilinearFormExtension::FillOperator(mfem_amd_pa_operator &op) const
    op.offsets = R->Offsets().Read(); op.indices = R->Indices().Read();
    op.yE = localY.Write();
    op.direct_rows = op.vdim == 0 ? R->DirectRows() : 0;
+   op.packed_indices = (op.direct_rows > 0 && R->PackedIndices().Size()) ? R->PackedIndices().Read() : nullptr;
    return true;
 }
 
@@ -1051,7 +1063,7 @@ bool CGSolver::FusedMult(const Vector &b, Vector &x) const
    const int n = width;
    MFEM_VERIFY(b.Size() == n && x.Size() == n, "incompatible sizes");
    const int64_t wsb = mfem_amd_pcg_workspace_bytes(n, max_iter);
-   ws.SetSize((int)((wsb + 7)/8));
+   ws.SetSize((wsb + 7)/8);
    history.assign((size_t)std::max(max_iter, 1) + 2, 0.0);
    mfem_amd_pcg_result res;
    const Vector *rhs = &b;

@@ -29,7 +29,7 @@ Vector &Vector::operator=(const Vector &v)
 }
 Vector &Vector::operator=(real_t value)
 {
-   const int n = Size();
+   const int64_t n = Size64();
    if (n == 0) { return *this; }
    if (data.OnDevice()) { MFEM_AMD_CALL(mfem_amd_vec_fill(n, value, data.Write(), nullptr)); }
    else { real_t *p = data.HostWrite(); std::fill(p, p + n, value); }   // not yet on the device: plain fill

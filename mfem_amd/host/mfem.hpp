@@ -60,13 +60,23 @@ void CopyOnDevice(void *dst, const void *src, size_t bytes);
 void CopyRowsOnDevice(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t rows);
 void DeviceSync();
 
-/// Host buffer + lazily created device mirror with validity flags: the semantics of
-/// Memory<T>::Read/Write/ReadWrite (general/device.hpp:352-400).
+/// Host buffer + device mirror, both created on first use, with validity flags: the semantics of
+/// Memory<T>::Read/Write/ReadWrite (general/device.hpp:352-400).  Sizes are 64-bit -- the reference's containers
+/// index with int (linalg/dtensor.hpp:32,121; general/array.hpp), which cannot hold BP3's pa_data at 1e8 dofs -- and a
+/// buffer that is only ever written and read on the device (pa_data, E-vectors) never gets a host allocation.
 template <class T> class Dual
 {
    mutable T *h = nullptr, *d = nullptr;
-   int n = 0, cap = 0;
+   int64_t n = 0, cap = 0;
    mutable bool hv = true, dv = false;
+   void EnsureHost() const
+   {
+      if (!h && cap > 0)
+      {
+         h = (T*)std::malloc(sizeof(T)*(size_t)cap);
+         MFEM_VERIFY(h, "out of host memory (" << sizeof(T)*(size_t)cap << " bytes)");
+      }
+   }
 public:
    Dual() {}
    ~Dual() { Destroy(); }
@@ -74,36 +84,47 @@ public:
    Dual &operator=(const Dual &o) { if (this != &o) { CopyFrom(o); } return *this; }
    Dual(Dual &&o) noexcept { Steal(o); }
    Dual &operator=(Dual &&o) noexcept { if (this != &o) { Destroy(); Steal(o); } return *this; }
-   int Size() const { return n; }
-   int Capacity() const { return cap; }
+   /// the reference's int-valued size; aborts (instead of wrapping) when the buffer is larger: use Size64()
+   int Size() const
+   {
+      MFEM_VERIFY(n <= (int64_t)2147483647, "mfem_amd: a buffer of " << n << " entries has no int size: use Size64()");
+      return (int)n;
+   }
+   int64_t Size64() const { return n; }
+   int64_t Capacity() const { return cap; }
    void Destroy()
    {
       std::free(h); if (d) { DeviceFree(d); }
       h = d = nullptr; n = cap = 0; hv = true; dv = false;
    }
    /// Resize; contents are kept only if @a keep (and only the valid side).
-   void SetSize(int nn, bool keep = false)
+   void SetSize(int64_t nn, bool keep = false)
    {
       MFEM_VERIFY(nn >= 0, "negative size");
       if (nn <= cap) { n = nn; return; }
-      int ncap = keep ? std::max(nn, 2*cap) : nn;
-      T *nh = (T*)std::malloc(sizeof(T)*(size_t)std::max(ncap, 1));
-      MFEM_VERIFY(nh, "out of host memory");
-      if (keep && n > 0) { std::memcpy(nh, HostRead(), sizeof(T)*(size_t)n); }
+      const int64_t ncap = keep ? std::max(nn, 2*cap) : nn;
+      T *nh = nullptr;
+      if (keep && n > 0)
+      {
+         nh = (T*)std::malloc(sizeof(T)*(size_t)ncap);
+         MFEM_VERIFY(nh, "out of host memory");
+         std::memcpy(nh, HostRead(), sizeof(T)*(size_t)n);
+      }
       std::free(h); if (d) { DeviceFree(d); d = nullptr; }
       h = nh; cap = ncap; n = nn; hv = true; dv = false;
    }
    const T *HostRead() const
    {
+      EnsureHost();
       if (!hv) { CopyToHost(h, d, sizeof(T)*(size_t)n); hv = true; }
       return h;
    }
-   T *HostWrite() { hv = true; dv = false; return h; }
+   T *HostWrite() { EnsureHost(); hv = true; dv = false; return h; }
    T *HostReadWrite() { HostRead(); dv = false; return h; }
    const T *Read() const
    {
       if (!d && cap > 0) { d = (T*)DeviceAlloc(sizeof(T)*(size_t)cap); }
-      if (!dv && n > 0) { CopyToDevice(d, h, sizeof(T)*(size_t)n); }
+      if (!dv && n > 0) { EnsureHost(); CopyToDevice(d, h, sizeof(T)*(size_t)n); }
       dv = true;
       return d;
    }
@@ -119,7 +140,7 @@ private:
    {
       SetSize(o.n);
       if (o.dv && !o.hv) { if (n > 0) { CopyOnDevice(Write(), o.d, sizeof(T)*(size_t)n); } }
-      else { if (n > 0) { std::memcpy(HostWrite(), o.h, sizeof(T)*(size_t)n); } }
+      else if (n > 0 && o.h) { std::memcpy(HostWrite(), o.h, sizeof(T)*(size_t)n); }
    }
    void Steal(Dual &o)
    {
@@ -138,7 +159,8 @@ public:
    explicit Array(int n) { mem.SetSize(n); }
    Array(const T *src, int n) { mem.SetSize(n); std::copy(src, src + n, mem.HostWrite()); }
    int Size() const { return mem.Size(); }
-   void SetSize(int n) { mem.SetSize(n, true); }
+   void SetSize(int64_t n) { mem.SetSize(n, true); }
+   int64_t Size64() const { return mem.Size64(); }
    void SetSize(int n, const T &init)
    { int o = Size(); mem.SetSize(n, true); T *p = mem.HostReadWrite(); for (int i = o; i < n; i++) { p[i] = init; } }
    void Reserve(int n) { int s = Size(); if (n > mem.Capacity()) { mem.SetSize(n, true); mem.SetSize(s, true); } }
@@ -241,12 +263,15 @@ protected:
 public:
    Vector() {}
    explicit Vector(int s) { data.SetSize(s); }
+   explicit Vector(int64_t s) { data.SetSize(s); }
    Vector(const Vector &) = default;
    Vector(Vector &&) = default;
    Vector &operator=(Vector &&) = default;
    virtual ~Vector() {}
    int Size() const { return data.Size(); }
-   void SetSize(int s) { data.SetSize(s, true); }
+   /// 64-bit size (device-resident quadrature data can pass 2^31 entries; Size() aborts there)
+   int64_t Size64() const { return data.Size64(); }
+   void SetSize(int64_t s) { data.SetSize(s, true); }
    void UseDevice(bool) {}
    bool UseDevice() const { return true; }
    void Destroy() { data.Destroy(); }
@@ -848,12 +873,15 @@ class ElementRestriction : public Operator
    const FiniteElementSpace &fes;
    int ne, vdim, ndofs, dof; bool byvdim;
    Array<int> offsets, indices, gather_map;
+   mutable Array<int> packed_indices;       // built on first use (a device kernel: host-only tools never ask for it)
    long long direct_rows = 0;
 public:
    ElementRestriction(const FiniteElementSpace &, ElementDofOrdering);
    /// NE*(D1D-2)^3 when the last L-dofs are the element-interior dofs, element by element in lexicographic order (the
    /// native H1 numbering puts them there), else 0: rows the PA element kernel writes itself (mfem_amd_interior_rows)
    long long DirectRows() const { return direct_rows; }
+   /// `indices` for the packed work E-vector that goes with the direct rows (mfem_amd_pack_indices); empty without them
+   const Array<int> &PackedIndices() const;
    void Mult(const Vector &x, Vector &y) const override;
    void MultTranspose(const Vector &x, Vector &y) const override;
    void AddMultTranspose(const Vector &x, Vector &y, const real_t a = 1.0) const;

@@ -77,8 +77,15 @@ class BoxPartition:
     """Local problem and shared-dof tables of rank `rank` in a (PX,PY,PZ) box grid with
     n = (nx,ny,nz) elements per rank and H1 order p."""
 
-    def __init__(self, p, n, pgrid, rank, extent=(1.0, 1.0, 1.0)):
+    def __init__(self, p, n, pgrid, rank, extent=(1.0, 1.0, 1.0), numbering="lexicographic"):
+        """numbering = "interior-last": the local elements are ordered interior first (those that touch no ghost dof:
+        their part of an apply can run while the owner -> ghost exchange is in flight), and the local L-dofs are
+        renumbered vertex/edge/face dofs first (in grid order), then the element-interior dofs element by element -- the
+        class of numberings the reference gives every H1 space (fem/fespace.cpp) -- so that the element kernel writes
+        those rows itself and the work E-vector is packed (include/mfem_amd.h: mfem_amd_interior_rows,
+        mfem_amd_pack_indices), exactly as on one GPU.  self.perm[grid id] = local id (None for the grid numbering)."""
         self.p, self.n, self.pgrid, self.rank = p, tuple(n), tuple(pgrid), rank
+        self.perm = None
         PX, PY, PZ = pgrid
         self.coord = (rank % PX, (rank//PX) % PY, rank//(PX*PY))
         gn = (PX*n[0], PY*n[1], PZ*n[2])
@@ -117,7 +124,47 @@ class BoxPartition:
         for off in itertools.product((0, -1), repeat=3):
             if any(off) and all(has_lo[d] for d in range(3) if off[d]):
                 self.lower.append((nbr_rank(off), index_set(off)))
+        if numbering == "mfem":
+            # the reference's numbering and element order for the local box (what ParFiniteElementSpace gives a rank:
+            # its own vertex / edge / face / interior numbering of its own elements), tables from the C++ host layer
+            from .hosttables import MfemBox
+            self.prob = MfemBox(p, n[0], n[1], n[2], extent[0], extent[1], extent[2], origin=origin, global_n=gn)
+            self.perm = self.prob.perm
+            self.upper = [(r, self.perm[ids].astype(np.int32)) for r, ids in self.upper]
+            self.lower = [(r, self.perm[ids].astype(np.int32)) for r, ids in self.lower]
+        if numbering in ("interior-last", "mfem") and p >= 2:
+            self._renumber_interior_last()
         _finish_shared_tables(self, self.prob.ndofs)
+
+    def _renumber_interior_last(self):
+        pr, D = self.prob, self.p + 1
+        nd, ni = D**3, (D - 2)**3
+        gm = np.asarray(pr.gather_map).reshape(pr.ne, nd)
+        ghost = np.zeros(pr.ndofs, bool)
+        for _, ids in self.lower:
+            ghost[ids] = True
+        iface = ghost[gm].any(axis=1)
+        eperm = np.concatenate([np.flatnonzero(~iface), np.flatnonzero(iface)])     # interior elements first, stable
+        gm = gm[eperm]
+        pr.nodes_E = np.ascontiguousarray(np.asarray(pr.nodes_E).reshape(pr.ne, -1)[eperm].reshape(-1))
+        inter = gm.reshape(pr.ne, D, D, D)[:, 1:-1, 1:-1, 1:-1].reshape(-1)          # (element, lexicographic interior index)
+        is_int = np.zeros(pr.ndofs, bool)
+        is_int[inter] = True
+        i0 = pr.ndofs - pr.ne*ni
+        perm = np.empty(pr.ndofs, np.int64)
+        perm[~is_int] = np.arange(i0)
+        perm[inter] = i0 + np.arange(pr.ne*ni)
+        # (composed with a numbering applied before: self.perm maps grid ids all the way)
+        self.perm = perm if self.perm is None else perm[self.perm]
+        self.element_order = eperm
+        pr.gather_map = np.ascontiguousarray(perm[gm.reshape(-1)].astype(np.int32))
+        # E -> L table of the new order: per dof, ascending E-vector position (fem/restriction.cpp:86-99)
+        pr.indices = np.argsort(pr.gather_map, kind="stable").astype(np.int32)
+        pr.offsets = np.zeros(pr.ndofs + 1, np.int32)
+        np.cumsum(np.bincount(pr.gather_map, minlength=pr.ndofs), out=pr.offsets[1:])
+        # the shared sets keep their order (both sides list them in grid order), only the ids change
+        self.upper = [(r, perm[ids].astype(np.int32)) for r, ids in self.upper]
+        self.lower = [(r, perm[ids].astype(np.int32)) for r, ids in self.lower]
 
     def local_to_global(self):
         """global lexicographic dof id of every local L-dof (tests)."""
@@ -126,11 +173,19 @@ class BoxPartition:
         g1 = (p*PX*self.n[0] + 1, p*PY*self.n[1] + 1, p*PZ*self.n[2] + 1)
         o = [self.coord[d]*self.n[d]*p for d in range(3)]
         ix, iy, iz = np.arange(n1[0]) + o[0], np.arange(n1[1]) + o[1], np.arange(n1[2]) + o[2]
-        return (ix[None, None, :] + g1[0]*(iy[None, :, None] + g1[1]*iz[:, None, None])).reshape(-1), g1
+        l2g = (ix[None, None, :] + g1[0]*(iy[None, :, None] + g1[1]*iz[:, None, None])).reshape(-1)
+        if self.perm is not None:
+            out = np.empty_like(l2g)
+            out[self.perm] = l2g
+            l2g = out
+        return l2g, g1
 
     def essential_marker(self):
         """1 = essential & owned, 2 = essential ghost copy, 0 otherwise; plus the dof list."""
-        ess = self.prob.boundary_dofs()
+        grid = getattr(self.prob, "_grid", self.prob)          # (boundary_dofs of the grid numbering, mapped below)
+        ess = grid.boundary_dofs()
+        if self.perm is not None:
+            ess = np.sort(self.perm[ess]).astype(np.int32)
         m = np.zeros(self.prob.ndofs, np.uint8)
         m[ess] = 1
         m[ess[self.ghost[ess]]] = 2

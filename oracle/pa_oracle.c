@@ -461,117 +461,141 @@ void orc_mass_setup_3d(int Q, int64_t ne, const double *W, const double *detJ,
  * PADiffusionApply3D (fem/integ/bilininteg_diffusion_kernels.hpp:795-985), the
  * reference's host loop nest; symmetric D.  Y += A_e X.
  * ------------------------------------------------------------------------------ */
+/* one element; D1D, Q1D are literals in the specialised calls below (the compiler then unrolls what the reference's
+ * templated kernels unroll), run-time values in the generic one: the same additions in the same order either way */
+static inline __attribute__((always_inline))
+void diffusion_apply_elem(const int D1D, const int Q1D, const int symmetric, const double *B, const double *G,
+                          const double *D, const double *X, double *Y, double (*grad)[3])
+{
+   const int64_t Q3 = (int64_t)Q1D*Q1D*Q1D;
+   double gradXY[MAXQ][MAXQ][3], gradX[MAXQ][3];
+   for (int64_t q = 0; q < Q3; q++) { grad[q][0] = grad[q][1] = grad[q][2] = 0.0; }
+   for (int dz = 0; dz < D1D; ++dz)
+   {
+      for (int qy = 0; qy < Q1D; ++qy)
+         for (int qx = 0; qx < Q1D; ++qx)
+         { gradXY[qy][qx][0] = gradXY[qy][qx][1] = gradXY[qy][qx][2] = 0.0; }
+      for (int dy = 0; dy < D1D; ++dy)
+      {
+         for (int qx = 0; qx < Q1D; ++qx) { gradX[qx][0] = gradX[qx][1] = 0.0; }
+         for (int dx = 0; dx < D1D; ++dx)
+         {
+            const double s = X[dx + D1D*(dy + D1D*dz)];
+            for (int qx = 0; qx < Q1D; ++qx)
+            {
+               gradX[qx][0] += s*B[qx + Q1D*dx];
+               gradX[qx][1] += s*G[qx + Q1D*dx];
+            }
+         }
+         for (int qy = 0; qy < Q1D; ++qy)
+         {
+            const double wy = B[qy + Q1D*dy], wDy = G[qy + Q1D*dy];
+            for (int qx = 0; qx < Q1D; ++qx)
+            {
+               const double wx = gradX[qx][0], wDx = gradX[qx][1];
+               gradXY[qy][qx][0] += wDx*wy;
+               gradXY[qy][qx][1] += wx*wDy;
+               gradXY[qy][qx][2] += wx*wy;
+            }
+         }
+      }
+      for (int qz = 0; qz < Q1D; ++qz)
+      {
+         const double wz = B[qz + Q1D*dz], wDz = G[qz + Q1D*dz];
+         for (int qy = 0; qy < Q1D; ++qy)
+            for (int qx = 0; qx < Q1D; ++qx)
+            {
+               double *g = grad[qx + Q1D*(qy + Q1D*qz)];
+               g[0] += gradXY[qy][qx][0]*wz;
+               g[1] += gradXY[qy][qx][1]*wz;
+               g[2] += gradXY[qy][qx][2]*wDz;
+            }
+      }
+   }
+   for (int64_t q = 0; q < Q3; q++)
+   {
+      /* plane order, symmetric and full (:903-911) */
+      const double O11 = D[q + 0*Q3], O12 = D[q + 1*Q3], O13 = D[q + 2*Q3];
+      const double O21 = symmetric ? O12 : D[q + 3*Q3];
+      const double O22 = symmetric ? D[q + 3*Q3] : D[q + 4*Q3];
+      const double O23 = symmetric ? D[q + 4*Q3] : D[q + 5*Q3];
+      const double O31 = symmetric ? O13 : D[q + 6*Q3];
+      const double O32 = symmetric ? O23 : D[q + 7*Q3];
+      const double O33 = symmetric ? D[q + 5*Q3] : D[q + 8*Q3];
+      const double gX = grad[q][0], gY = grad[q][1], gZ = grad[q][2];
+      grad[q][0] = (O11*gX) + (O12*gY) + (O13*gZ);
+      grad[q][1] = (O21*gX) + (O22*gY) + (O23*gZ);
+      grad[q][2] = (O31*gX) + (O32*gY) + (O33*gZ);
+   }
+   for (int qz = 0; qz < Q1D; ++qz)
+   {
+      double gXY[MAXQ][MAXQ][3];
+      for (int dy = 0; dy < D1D; ++dy)
+         for (int dx = 0; dx < D1D; ++dx)
+         { gXY[dy][dx][0] = gXY[dy][dx][1] = gXY[dy][dx][2] = 0; }
+      for (int qy = 0; qy < Q1D; ++qy)
+      {
+         double gXd[MAXQ][3];
+         for (int dx = 0; dx < D1D; ++dx) { gXd[dx][0] = gXd[dx][1] = gXd[dx][2] = 0; }
+         for (int qx = 0; qx < Q1D; ++qx)
+         {
+            const double *g = grad[qx + Q1D*(qy + Q1D*qz)];
+            for (int dx = 0; dx < D1D; ++dx)
+            {
+               const double wx = B[qx + Q1D*dx], wDx = G[qx + Q1D*dx];
+               gXd[dx][0] += g[0]*wDx;
+               gXd[dx][1] += g[1]*wx;
+               gXd[dx][2] += g[2]*wx;
+            }
+         }
+         for (int dy = 0; dy < D1D; ++dy)
+         {
+            const double wy = B[qy + Q1D*dy], wDy = G[qy + Q1D*dy];
+            for (int dx = 0; dx < D1D; ++dx)
+            {
+               gXY[dy][dx][0] += gXd[dx][0]*wy;
+               gXY[dy][dx][1] += gXd[dx][1]*wDy;
+               gXY[dy][dx][2] += gXd[dx][2]*wy;
+            }
+         }
+      }
+      for (int dz = 0; dz < D1D; ++dz)
+      {
+         const double wz = B[qz + Q1D*dz], wDz = G[qz + Q1D*dz];
+         for (int dy = 0; dy < D1D; ++dy)
+            for (int dx = 0; dx < D1D; ++dx)
+            {
+               Y[dx + D1D*(dy + D1D*dz)] +=
+                  ((gXY[dy][dx][0]*wz) + (gXY[dy][dx][1]*wz) + (gXY[dy][dx][2]*wDz));
+            }
+      }
+   }
+}
+
+#define ORC_REGISTERED_SHAPES(F) F(2,2) F(2,3) F(3,3) F(3,4) F(4,4) F(4,5) F(5,5) F(5,6) F(6,6) F(6,7) F(7,7) F(7,8) F(8,8) F(8,9) \
+                                 F(9,9) F(9,10) F(4,6) F(5,8)
+
 static void diffusion_apply_3d(int D1D, int Q1D, int64_t ne, int symmetric, const double *B,
                                const double *G, const double *Dd, const double *Xd,
                                double *Yd)
 {
    const int64_t D3 = (int64_t)D1D*D1D*D1D, Q3 = (int64_t)Q1D*Q1D*Q1D;
-   #pragma omp parallel for schedule(static)
-   for (int64_t e = 0; e < ne; e++)
+   #pragma omp parallel
    {
-      const double *X = Xd + D3*e, *D = Dd + (symmetric ? 6 : 9)*Q3*e;
-      double *Y = Yd + D3*e;
-      double (*grad)[3] = (double(*)[3])malloc(sizeof(double)*3*Q3);
-      double gradXY[MAXQ][MAXQ][3], gradX[MAXQ][3];
-      for (int64_t q = 0; q < Q3; q++) { grad[q][0] = grad[q][1] = grad[q][2] = 0.0; }
-      for (int dz = 0; dz < D1D; ++dz)
+      double (*grad)[3] = (double(*)[3])malloc(sizeof(double)*3*Q3);      /* per thread, not per element */
+#define ORC_CASE(DD, QQ) \
+      if (D1D == DD && Q1D == QQ && symmetric) \
+      { \
+         _Pragma("omp for schedule(static)") \
+         for (int64_t e = 0; e < ne; e++) { diffusion_apply_elem(DD, QQ, 1, B, G, Dd + 6*Q3*e, Xd + D3*e, Yd + D3*e, grad); } \
+      } else
+      ORC_REGISTERED_SHAPES(ORC_CASE)
+#undef ORC_CASE
       {
-         for (int qy = 0; qy < Q1D; ++qy)
-            for (int qx = 0; qx < Q1D; ++qx)
-            { gradXY[qy][qx][0] = gradXY[qy][qx][1] = gradXY[qy][qx][2] = 0.0; }
-         for (int dy = 0; dy < D1D; ++dy)
+         #pragma omp for schedule(static)
+         for (int64_t e = 0; e < ne; e++)
          {
-            for (int qx = 0; qx < Q1D; ++qx) { gradX[qx][0] = gradX[qx][1] = 0.0; }
-            for (int dx = 0; dx < D1D; ++dx)
-            {
-               const double s = X[dx + D1D*(dy + D1D*dz)];
-               for (int qx = 0; qx < Q1D; ++qx)
-               {
-                  gradX[qx][0] += s*B[qx + Q1D*dx];
-                  gradX[qx][1] += s*G[qx + Q1D*dx];
-               }
-            }
-            for (int qy = 0; qy < Q1D; ++qy)
-            {
-               const double wy = B[qy + Q1D*dy], wDy = G[qy + Q1D*dy];
-               for (int qx = 0; qx < Q1D; ++qx)
-               {
-                  const double wx = gradX[qx][0], wDx = gradX[qx][1];
-                  gradXY[qy][qx][0] += wDx*wy;
-                  gradXY[qy][qx][1] += wx*wDy;
-                  gradXY[qy][qx][2] += wx*wy;
-               }
-            }
-         }
-         for (int qz = 0; qz < Q1D; ++qz)
-         {
-            const double wz = B[qz + Q1D*dz], wDz = G[qz + Q1D*dz];
-            for (int qy = 0; qy < Q1D; ++qy)
-               for (int qx = 0; qx < Q1D; ++qx)
-               {
-                  double *g = grad[qx + Q1D*(qy + Q1D*qz)];
-                  g[0] += gradXY[qy][qx][0]*wz;
-                  g[1] += gradXY[qy][qx][1]*wz;
-                  g[2] += gradXY[qy][qx][2]*wDz;
-               }
-         }
-      }
-      for (int64_t q = 0; q < Q3; q++)
-      {
-         /* plane order, symmetric and full (:903-911) */
-         const double O11 = D[q + 0*Q3], O12 = D[q + 1*Q3], O13 = D[q + 2*Q3];
-         const double O21 = symmetric ? O12 : D[q + 3*Q3];
-         const double O22 = symmetric ? D[q + 3*Q3] : D[q + 4*Q3];
-         const double O23 = symmetric ? D[q + 4*Q3] : D[q + 5*Q3];
-         const double O31 = symmetric ? O13 : D[q + 6*Q3];
-         const double O32 = symmetric ? O23 : D[q + 7*Q3];
-         const double O33 = symmetric ? D[q + 5*Q3] : D[q + 8*Q3];
-         const double gX = grad[q][0], gY = grad[q][1], gZ = grad[q][2];
-         grad[q][0] = (O11*gX) + (O12*gY) + (O13*gZ);
-         grad[q][1] = (O21*gX) + (O22*gY) + (O23*gZ);
-         grad[q][2] = (O31*gX) + (O32*gY) + (O33*gZ);
-      }
-      for (int qz = 0; qz < Q1D; ++qz)
-      {
-         double gXY[MAXQ][MAXQ][3];
-         for (int dy = 0; dy < D1D; ++dy)
-            for (int dx = 0; dx < D1D; ++dx)
-            { gXY[dy][dx][0] = gXY[dy][dx][1] = gXY[dy][dx][2] = 0; }
-         for (int qy = 0; qy < Q1D; ++qy)
-         {
-            double gXd[MAXQ][3];
-            for (int dx = 0; dx < D1D; ++dx) { gXd[dx][0] = gXd[dx][1] = gXd[dx][2] = 0; }
-            for (int qx = 0; qx < Q1D; ++qx)
-            {
-               const double *g = grad[qx + Q1D*(qy + Q1D*qz)];
-               for (int dx = 0; dx < D1D; ++dx)
-               {
-                  const double wx = B[qx + Q1D*dx], wDx = G[qx + Q1D*dx];
-                  gXd[dx][0] += g[0]*wDx;
-                  gXd[dx][1] += g[1]*wx;
-                  gXd[dx][2] += g[2]*wx;
-               }
-            }
-            for (int dy = 0; dy < D1D; ++dy)
-            {
-               const double wy = B[qy + Q1D*dy], wDy = G[qy + Q1D*dy];
-               for (int dx = 0; dx < D1D; ++dx)
-               {
-                  gXY[dy][dx][0] += gXd[dx][0]*wy;
-                  gXY[dy][dx][1] += gXd[dx][1]*wDy;
-                  gXY[dy][dx][2] += gXd[dx][2]*wy;
-               }
-            }
-         }
-         for (int dz = 0; dz < D1D; ++dz)
-         {
-            const double wz = B[qz + Q1D*dz], wDz = G[qz + Q1D*dz];
-            for (int dy = 0; dy < D1D; ++dy)
-               for (int dx = 0; dx < D1D; ++dx)
-               {
-                  Y[dx + D1D*(dy + D1D*dz)] +=
-                     ((gXY[dy][dx][0]*wz) + (gXY[dy][dx][1]*wz) + (gXY[dy][dx][2]*wDz));
-               }
+            diffusion_apply_elem(D1D, Q1D, symmetric, B, G, Dd + (symmetric ? 6 : 9)*Q3*e, Xd + D3*e, Yd + D3*e, grad);
          }
       }
       free(grad);
@@ -597,71 +621,87 @@ void orc_diffusion_apply_sym_3d(int D1D, int Q1D, int64_t ne, int symmetric, con
  * PAMassApply3D_Element (fem/integ/bilininteg_mass_kernels.hpp:656-805), host loop nest.
  * Y += B^T diag(D) B X.
  * ------------------------------------------------------------------------------ */
+static inline __attribute__((always_inline))
+void mass_apply_elem(const int D1D, const int Q1D, const double *B, const double *D, const double *X, double *Y, double *sol_xyz)
+{
+   const int64_t Q3 = (int64_t)Q1D*Q1D*Q1D;
+   for (int64_t q = 0; q < Q3; q++) { sol_xyz[q] = 0.0; }
+   double sol_xy[MAXQ][MAXQ], sol_x[MAXQ];
+   for (int dz = 0; dz < D1D; ++dz)
+   {
+      for (int qy = 0; qy < Q1D; ++qy)
+         for (int qx = 0; qx < Q1D; ++qx) { sol_xy[qy][qx] = 0; }
+      for (int dy = 0; dy < D1D; ++dy)
+      {
+         for (int qx = 0; qx < Q1D; ++qx) { sol_x[qx] = 0; }
+         for (int dx = 0; dx < D1D; ++dx)
+         {
+            const double s = X[dx + D1D*(dy + D1D*dz)];
+            for (int qx = 0; qx < Q1D; ++qx) { sol_x[qx] += B[qx + Q1D*dx]*s; }
+         }
+         for (int qy = 0; qy < Q1D; ++qy)
+         {
+            const double wy = B[qy + Q1D*dy];
+            for (int qx = 0; qx < Q1D; ++qx) { sol_xy[qy][qx] += wy*sol_x[qx]; }
+         }
+      }
+      for (int qz = 0; qz < Q1D; ++qz)
+      {
+         const double wz = B[qz + Q1D*dz];
+         for (int qy = 0; qy < Q1D; ++qy)
+            for (int qx = 0; qx < Q1D; ++qx)
+            { sol_xyz[qx + Q1D*(qy + Q1D*qz)] += wz*sol_xy[qy][qx]; }
+      }
+   }
+   for (int64_t q = 0; q < Q3; q++) { sol_xyz[q] *= D[q]; }
+   for (int qz = 0; qz < Q1D; ++qz)
+   {
+      double s_xy[MAXQ][MAXQ];
+      for (int dy = 0; dy < D1D; ++dy)
+         for (int dx = 0; dx < D1D; ++dx) { s_xy[dy][dx] = 0; }
+      for (int qy = 0; qy < Q1D; ++qy)
+      {
+         double s_x[MAXQ];
+         for (int dx = 0; dx < D1D; ++dx) { s_x[dx] = 0; }
+         for (int qx = 0; qx < Q1D; ++qx)
+         {
+            const double s = sol_xyz[qx + Q1D*(qy + Q1D*qz)];
+            for (int dx = 0; dx < D1D; ++dx) { s_x[dx] += B[qx + Q1D*dx]*s; }
+         }
+         for (int dy = 0; dy < D1D; ++dy)
+         {
+            const double wy = B[qy + Q1D*dy];
+            for (int dx = 0; dx < D1D; ++dx) { s_xy[dy][dx] += wy*s_x[dx]; }
+         }
+      }
+      for (int dz = 0; dz < D1D; ++dz)
+      {
+         const double wz = B[qz + Q1D*dz];
+         for (int dy = 0; dy < D1D; ++dy)
+            for (int dx = 0; dx < D1D; ++dx)
+            { Y[dx + D1D*(dy + D1D*dz)] += wz*s_xy[dy][dx]; }
+      }
+   }
+}
+
 void orc_mass_apply_3d(int D1D, int Q1D, int64_t ne, const double *B, const double *Dd,
                        const double *Xd, double *Yd)
 {
    const int64_t D3 = (int64_t)D1D*D1D*D1D, Q3 = (int64_t)Q1D*Q1D*Q1D;
-   #pragma omp parallel for schedule(static)
-   for (int64_t e = 0; e < ne; e++)
+   #pragma omp parallel
    {
-      const double *X = Xd + D3*e, *D = Dd + Q3*e;
-      double *Y = Yd + D3*e;
-      double *sol_xyz = (double*)calloc(Q3, sizeof(double));
-      double sol_xy[MAXQ][MAXQ], sol_x[MAXQ];
-      for (int dz = 0; dz < D1D; ++dz)
+      double *sol_xyz = (double*)malloc(sizeof(double)*Q3);               /* per thread, not per element */
+#define ORC_CASE(DD, QQ) \
+      if (D1D == DD && Q1D == QQ) \
+      { \
+         _Pragma("omp for schedule(static)") \
+         for (int64_t e = 0; e < ne; e++) { mass_apply_elem(DD, QQ, B, Dd + Q3*e, Xd + D3*e, Yd + D3*e, sol_xyz); } \
+      } else
+      ORC_REGISTERED_SHAPES(ORC_CASE) ORC_CASE(2, 4) ORC_CASE(3, 6)
+#undef ORC_CASE
       {
-         for (int qy = 0; qy < Q1D; ++qy)
-            for (int qx = 0; qx < Q1D; ++qx) { sol_xy[qy][qx] = 0; }
-         for (int dy = 0; dy < D1D; ++dy)
-         {
-            for (int qx = 0; qx < Q1D; ++qx) { sol_x[qx] = 0; }
-            for (int dx = 0; dx < D1D; ++dx)
-            {
-               const double s = X[dx + D1D*(dy + D1D*dz)];
-               for (int qx = 0; qx < Q1D; ++qx) { sol_x[qx] += B[qx + Q1D*dx]*s; }
-            }
-            for (int qy = 0; qy < Q1D; ++qy)
-            {
-               const double wy = B[qy + Q1D*dy];
-               for (int qx = 0; qx < Q1D; ++qx) { sol_xy[qy][qx] += wy*sol_x[qx]; }
-            }
-         }
-         for (int qz = 0; qz < Q1D; ++qz)
-         {
-            const double wz = B[qz + Q1D*dz];
-            for (int qy = 0; qy < Q1D; ++qy)
-               for (int qx = 0; qx < Q1D; ++qx)
-               { sol_xyz[qx + Q1D*(qy + Q1D*qz)] += wz*sol_xy[qy][qx]; }
-         }
-      }
-      for (int64_t q = 0; q < Q3; q++) { sol_xyz[q] *= D[q]; }
-      for (int qz = 0; qz < Q1D; ++qz)
-      {
-         double s_xy[MAXQ][MAXQ];
-         for (int dy = 0; dy < D1D; ++dy)
-            for (int dx = 0; dx < D1D; ++dx) { s_xy[dy][dx] = 0; }
-         for (int qy = 0; qy < Q1D; ++qy)
-         {
-            double s_x[MAXQ];
-            for (int dx = 0; dx < D1D; ++dx) { s_x[dx] = 0; }
-            for (int qx = 0; qx < Q1D; ++qx)
-            {
-               const double s = sol_xyz[qx + Q1D*(qy + Q1D*qz)];
-               for (int dx = 0; dx < D1D; ++dx) { s_x[dx] += B[qx + Q1D*dx]*s; }
-            }
-            for (int dy = 0; dy < D1D; ++dy)
-            {
-               const double wy = B[qy + Q1D*dy];
-               for (int dx = 0; dx < D1D; ++dx) { s_xy[dy][dx] += wy*s_x[dx]; }
-            }
-         }
-         for (int dz = 0; dz < D1D; ++dz)
-         {
-            const double wz = B[qz + Q1D*dz];
-            for (int dy = 0; dy < D1D; ++dy)
-               for (int dx = 0; dx < D1D; ++dx)
-               { Y[dx + D1D*(dy + D1D*dz)] += wz*s_xy[dy][dx]; }
-         }
+         #pragma omp for schedule(static)
+         for (int64_t e = 0; e < ne; e++) { mass_apply_elem(D1D, Q1D, B, Dd + Q3*e, Xd + D3*e, Yd + D3*e, sol_xyz); }
       }
       free(sol_xyz);
    }
@@ -979,9 +1019,34 @@ void orc_jacobi_setup(int64_t n, const double *diag, int ness, const int *ess, d
    for (int i = 0; i < ness; i++) { dinv[ess[i]] = 1.0; }
 }
 
+/* TIMING LEG ONLY (bench.py cpu_baseline): the vector updates and dot products of orc_pcg threaded as MFEM's `-d cpu` path
+ * with one MPI rank per core would run them -- every core updates its own contiguous block and sums its own part of a
+ * dot product sequentially (the rank-local Vector::operator*), the partial sums are added in block (= rank) order (the
+ * all-reduce).  The sum order differs from the single-rank sequential reference: never switched on by a parity test. */
+static int orc_threaded_vectors = 0;
+void orc_set_threaded_vectors(int on) { orc_threaded_vectors = on; }
+
 /* Vector::operator* on host: strictly sequential (general/reducers.hpp:589-592). */
 static double orc_dot(int64_t n, const double *a, const double *b)
 {
+   if (orc_threaded_vectors)
+   {
+      enum { MAXT = 1024 };
+      static double part[MAXT];
+      int T = omp_get_max_threads();
+      if (T > MAXT) { T = MAXT; }
+      #pragma omp parallel num_threads(T)
+      {
+         const int t = omp_get_thread_num();
+         const int64_t i0 = n*t/T, i1 = n*(t + 1)/T;
+         double s = 0.0;
+         for (int64_t i = i0; i < i1; i++) { s += a[i]*b[i]; }
+         part[t] = s;
+      }
+      double s = 0.0;
+      for (int t = 0; t < T; t++) { s += part[t]; }
+      return s;
+   }
    double s = 0.0;
    for (int64_t i = 0; i < n; i++) { s += a[i]*b[i]; }
    return s;
@@ -991,6 +1056,7 @@ static double orc_dot(int64_t n, const double *a, const double *b)
  * (linalg/solvers.cpp:869-1050; Jacobi Mult :427-453).  dinv == NULL -> unpreconditioned.
  * hist[k] = (B r, r) at iteration k (hist must hold max_iter+1 entries).
  * Returns the final iteration count; *converged is set as the reference sets it. */
+#define ORC_VLOOP _Pragma("omp parallel for schedule(static) if(orc_threaded_vectors)")
 int orc_pcg(const orc_op *op, const double *dinv, const double *b, double *x,
             double rel_tol, double abs_tol, int max_iter, double *hist, int *converged)
 {
@@ -1001,7 +1067,7 @@ int orc_pcg(const orc_op *op, const double *dinv, const double *b, double *x,
    int i, final_iter = 0;
    memcpy(r, b, sizeof(double)*n);
    memset(x, 0, sizeof(double)*n);
-   if (dinv) { for (int64_t k = 0; k < n; k++) { z[k] = 0.0 + dinv[k]*r[k]; d[k] = z[k]; } }
+   if (dinv) { ORC_VLOOP for (int64_t k = 0; k < n; k++) { z[k] = 0.0 + dinv[k]*r[k]; d[k] = z[k]; } }
    else { memcpy(d, r, sizeof(double)*n); }
    nom = orc_dot(n, d, r);
    if (hist) { hist[0] = nom; }
@@ -1016,11 +1082,11 @@ int orc_pcg(const orc_op *op, const double *dinv, const double *b, double *x,
    for (i = 1; 1; )
    {
       alpha = nom/den;
-      for (int64_t k = 0; k < n; k++) { x[k] = x[k] + alpha*d[k]; }
-      for (int64_t k = 0; k < n; k++) { r[k] = r[k] + (-alpha)*z[k]; }
+      ORC_VLOOP for (int64_t k = 0; k < n; k++) { x[k] = x[k] + alpha*d[k]; }
+      ORC_VLOOP for (int64_t k = 0; k < n; k++) { r[k] = r[k] + (-alpha)*z[k]; }
       if (dinv)
       {
-         for (int64_t k = 0; k < n; k++) { z[k] = 0.0 + dinv[k]*r[k]; }
+         ORC_VLOOP for (int64_t k = 0; k < n; k++) { z[k] = 0.0 + dinv[k]*r[k]; }
          betanom = orc_dot(n, r, z);
       }
       else { betanom = orc_dot(n, r, r); }
@@ -1029,8 +1095,8 @@ int orc_pcg(const orc_op *op, const double *dinv, const double *b, double *x,
       if (betanom <= r0) { *converged = 1; final_iter = i; break; }
       if (++i > max_iter) { break; }
       beta = betanom/nom;
-      if (dinv) { for (int64_t k = 0; k < n; k++) { d[k] = z[k] + beta*d[k]; } }
-      else { for (int64_t k = 0; k < n; k++) { d[k] = r[k] + beta*d[k]; } }
+      if (dinv) { ORC_VLOOP for (int64_t k = 0; k < n; k++) { d[k] = z[k] + beta*d[k]; } }
+      else { ORC_VLOOP for (int64_t k = 0; k < n; k++) { d[k] = r[k] + beta*d[k]; } }
       orc_constrained_mult(op, d, z);
       den = orc_dot(n, d, z);
       if (den == 0.0) { final_iter = i; break; }
@@ -1039,6 +1105,15 @@ int orc_pcg(const orc_op *op, const double *dinv, const double *b, double *x,
 done:
    free(r); free(d); free(z);
    return final_iter;
+}
+
+#undef ORC_VLOOP
+
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+   if (n > 0) { omp_set_num_threads(n); }
+#endif
 }
 
 int orc_num_threads(void)

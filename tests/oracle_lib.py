@@ -69,6 +69,8 @@ _sig("orc_jacobi_setup", None, i64, _d, C.c_int, _i, _d)
 _sig("orc_pcg", C.c_int, C.POINTER(OrcOp), C.c_void_p, _d, _d, C.c_double, C.c_double, C.c_int,
      _d, C.POINTER(C.c_int))
 _sig("orc_num_threads", C.c_int)
+_sig("orc_set_num_threads", None, C.c_int)
+_sig("orc_set_threaded_vectors", None, C.c_int)       # timing leg of bench.py only
 
 
 def gauss_legendre(n):

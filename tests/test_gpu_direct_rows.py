@@ -1,5 +1,5 @@
-"""-m gpu: element-interior rows written by the element kernel (include/mfem_amd.h: mfem_amd_interior_rows,
-mfem_amd_pa_apply_L2L, mfem_amd_pa_operator.direct_rows).  The values are the ones the E-vector would have carried
+"""-m gpu: element-interior rows written by the element kernel and the packed E-vector that goes with them
+(include/mfem_amd.h: mfem_amd_interior_rows, mfem_amd_pack_indices, mfem_amd_pa_apply_L2L, mfem_amd_pa_operator.direct_rows).  The values are the ones the E-vector would have carried
 and the rows have one entry each, so everything here is bit-exact against the plain two-kernel form; the PCG's dot
 product sums in another order and is held to 1e-12 relative."""
 import ctypes as C
@@ -47,12 +47,38 @@ def test_golden_meshes_direct_rows_bit_identical(gh, name, monkeypatch):
         assert dr == (NE*(D - 2)**3 if D >= 3 else 0), (name, dr)
         x = gh.dev(c["x"])
         y0 = gh.host(op.constrained_mult(x))
+        if not dr:
+            continue
+        # direct rows + the packed E-vector (mfem_amd_pack_indices): same values, same order of additions, same bits
+        pind = gh.zeros(op.ind.numel(), torch.int32)
+        capi.call("mfem_amd_pack_indices", D, op.ind.numel(), gh.ptr(op.ind), gh.ptr(pind), None)
+        ns = D**3 - (D - 2)**3
+        live = gh.host(pind)[:int(c["offsets"][n - dr])]
+        assert live.min() >= 0 and live.max() < NE*ns and len(np.unique(live)) == len(live) == NE*ns
         op.op.direct_rows = dr
-        y1 = gh.host(op.constrained_mult(x))
-        assert np.array_equal(y0, y1)
-        # stale E-vector entries of the interior positions are never read: poison them
+        assert np.array_equal(gh.host(op.constrained_mult(x)), y0)       # no table: the plain form still
+        op.op.packed_indices = pind.data_ptr()
+        # what lies beyond the NE*NS packed entries is never touched, and nothing stale is read: poison all of it
         op.yE.fill_(float("nan"))
         assert np.array_equal(gh.host(op.constrained_mult(x)), y0)
+        assert torch.isnan(op.yE[NE*ns:]).all() and not torch.isnan(op.yE[:NE*ns]).any()
+        # an element-interior dof in the essential list (a pinned dof): its row takes x like any other
+        ess2 = np.unique(np.concatenate([np.asarray(c["ess_tdof"], np.int64), [n - 1, n - dr, n - dr//2 - 1]])).astype(np.int32)
+        op2 = gh.DeviceOperator(c, ess2, layout=layout)
+        yref = gh.host(op2.constrained_mult(x))
+        assert np.array_equal(yref[ess2], c["x"][ess2])
+        op2.op.direct_rows = dr
+        op2.op.packed_indices = pind.data_ptr()
+        assert np.array_equal(gh.host(op2.constrained_mult(x)), yref)
+        # ... and inside the solver (the fused (d, A d) takes its direct-row part from the patched value)
+        dinv = gh.dev(1.0/np.where(np.abs(c["diag"]) > 0, c["diag"], 1.0)); dinv[gh.dev(ess2, np.int64)] = 1.0
+        b = gh.dev(np.where(np.isin(np.arange(n), ess2), 0.0, c["B_rhs"]))
+        op3 = gh.DeviceOperator(c, ess2, layout=layout)
+        X0, r0, h0 = op3.pcg(b, dinv, 1e-8, max_iter=300)
+        X1, r1, h1 = op2.pcg(b, dinv, 1e-8, max_iter=300)
+        assert r1.iterations == r0.iterations and r1.converged == r0.converged
+        assert np.max(np.abs(h1 - h0)) <= 1e-11*abs(h0[0])
+        assert torch.max(torch.abs(X1 - X0)).item() <= 1e-9*max(1e-300, torch.max(torch.abs(X0)).item())
     # a gather map that breaks the property anywhere is refused
     if D >= 3:
         gm = np.array(c["gather_map"], np.int32).reshape(NE, D, D, D)
@@ -109,6 +135,12 @@ def test_interior_last_numbering_matches_lexicographic(gh, problem, p, n, monkey
     il.mult(xi, yi)
     torch.cuda.synchronize()
     assert torch.equal(yi, y0)
+    assert il.pind is not None
+    # the two halves run separately (bench.py's kernel timings) give the same y too
+    yk = torch.full_like(xl, float("nan"))
+    il.l2e(xi, y=yk); il.e2l(yk)
+    torch.cuda.synchronize()
+    assert torch.equal(yk, y0)
 
 
 def test_l2l_rejects_bad_direct_rows(gh):
@@ -117,5 +149,12 @@ def test_l2l_rejects_bad_direct_rows(gh):
     op = gh.DeviceOperator(c, None)
     x, y = gh.dev(c["x"]), gh.zeros(c["ndofs"])
     rc = capi.lib.mfem_amd_pa_apply_L2L(c["kind"], 0, c["D1D"], c["Q1D"], c["NE"], c["ndofs"], op.B, op.G, gh.ptr(op.pa),
-                                        gh.ptr(op.gm), gh.ptr(op.off), gh.ptr(op.ind), 5, gh.ptr(x), gh.ptr(op.yE), gh.ptr(y), None)
+                                        gh.ptr(op.gm), gh.ptr(op.off), gh.ptr(op.ind), gh.ptr(op.ind), 5, gh.ptr(x), gh.ptr(op.yE),
+                                        gh.ptr(y), None)
     assert rc != 0 and b"direct_rows" in capi.lib.mfem_amd_last_error()
+    if c["D1D"] >= 3:
+        dr = c["NE"]*(c["D1D"] - 2)**3
+        rc = capi.lib.mfem_amd_pa_apply_L2L(c["kind"], 0, c["D1D"], c["Q1D"], c["NE"], c["ndofs"], op.B, op.G, gh.ptr(op.pa),
+                                            gh.ptr(op.gm), gh.ptr(op.off), gh.ptr(op.ind), None, dr, gh.ptr(x), gh.ptr(op.yE),
+                                            gh.ptr(y), None)
+        assert rc != 0 and b"packed_indices" in capi.lib.mfem_amd_last_error()

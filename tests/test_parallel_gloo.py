@@ -54,8 +54,15 @@ def _worker(rank, world, port, p, n, kind, out, mode="box"):
         from conftest import load_case, splitmix
         pg = process_grid(world)
         Q = p + 2
-        if mode == "box":
-            part = BoxPartition(p, (n, n, n), pg, rank)
+        if mode in ("box", "box-il", "box-mfem"):
+            # box-mfem: the reference's numbering of the local box (tables from the C++ host layer), interior elements
+            # first, element-interior dofs last -- what bench.py --gpus N runs on; box-il: the same on the grid numbering
+            part = BoxPartition(p, (n, n, n), pg, rank, numbering={"box": "lexicographic", "box-il": "interior-last",
+                                                                   "box-mfem": "mfem"}[mode])
+            if mode != "box":
+                ni = (p - 1)**3
+                gmi = part.prob.gather_map.reshape(part.prob.ne, p + 1, p + 1, p + 1)[:, 1:-1, 1:-1, 1:-1].reshape(-1)
+                assert np.array_equal(gmi, part.prob.ndofs - part.prob.ne*ni + np.arange(part.prob.ne*ni))
             # ---- serial problem on the global box (every rank builds it; small)
             gprob = CartesianProblem(p, pg[0]*n, pg[1]*n, pg[2]*n)
             gess = gprob.boundary_dofs()
@@ -154,6 +161,8 @@ def _worker(rank, world, port, p, n, kind, out, mode="box"):
 
 
 @pytest.mark.parametrize("world,p,n,kind,mode", [(2, 2, 2, 1, "box"), (2, 3, 2, 0, "box"), (8, 2, 2, 1, "box"), (4, 1, 3, 1, "box"),
+                                                 (2, 3, 2, 1, "box-il"), (8, 2, 2, 1, "box-il"), (4, 4, 2, 0, "box-il"),
+                                                 (2, 3, 3, 1, "box-mfem"), (8, 2, 2, 1, "box-mfem"), (4, 4, 2, 0, "box-mfem"),
                                                  (3, 2, 2, 1, "chunks"), (4, 2, 2, 1, "random"), (2, 3, 2, 0, "random"),
                                                  (2, 2, 0, 1, "toroid"), (3, 2, 0, 1, "toroid")])
 def test_partitioned_operator_and_pcg_match_serial(world, p, n, kind, mode):
