@@ -312,6 +312,10 @@ typedef struct mfem_amd_pa_operator
                                 L-rows are element-interior dofs, which the element kernel writes itself (scalar spaces) */
    const int *packed_indices;/* `indices` remapped by mfem_amd_pack_indices: the table of the packed work E-vector that goes
                                 with the direct rows (NULL: no direct rows, the plain two-kernel form) */
+   int64_t e_split;          /* partitioned runs (scalar spaces): the local elements [0, e_split) touch no ghost dof -- their
+                                part of the element kernel runs while the owner -> ghost exchange is in flight on a second
+                                stream; a multiple of the blocked layout's batch (mfem_amd_pa_data_size(kind, 1, Q1D, 1) /
+                                (C*Q1D^3) elements).  0: the exchange first, then all elements */
 } mfem_amd_pa_operator;
 
 /* Element-interior dofs belong to one element, so their rows of G^T are single entries: when they are the LAST

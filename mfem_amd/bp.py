@@ -66,8 +66,7 @@ class BakeoffProblem:
             self.e_split = (n_int//nbz)*nbz
             ordered = not iface[:n_int].any()          # the partition already lists its interior elements first
             if 0 < self.e_split and iface.any() and ordered:
-                self._cstream = torch.cuda.Stream(self.dev)
-                self._ev_x, self._ev_ghosts = torch.cuda.Event(), torch.cuda.Event()
+                pass
             elif 0 < self.e_split and iface.any():
                 perm = np.concatenate([np.flatnonzero(~iface), np.flatnonzero(iface)])
                 gmap = gmap[perm]
@@ -77,8 +76,6 @@ class BakeoffProblem:
                 indices = np.argsort(gather_map, kind="stable").astype(np.int32)
                 offsets = np.zeros(pr.ndofs + 1, np.int32)
                 np.cumsum(np.bincount(gather_map, minlength=pr.ndofs), out=offsets[1:])
-                self._cstream = torch.cuda.Stream(self.dev)
-                self._ev_x, self._ev_ghosts = torch.cuda.Event(), torch.cuda.Event()
             else:
                 self.e_split = 0
         self._nodes_E = nodes_E
@@ -148,6 +145,11 @@ class BakeoffProblem:
             self.pind = torch.empty_like(self.ind)
             capi.call("mfem_amd_pack_indices", D, self.ind.numel(), _p(self.ind), _p(self.pind), self.stream)
             self.op.packed_indices = self.pind.data_ptr()
+        # the library overlaps the owner -> ghost exchange with the first e_split elements (include/mfem_amd.h)
+        self.op.e_split = 0 if self.vdim else self.e_split
+        # BilinearForm::Mult is the unconstrained operator: the same tables without the essential list
+        self.op_free = capi.PaOperator.from_buffer_copy(self.op)
+        self.op_free.ness, self.op_free.ess, self.op_free.ess_marker, self.op_free.masked_gather_map = 0, None, None, None
         self.ghost = None
         if part is not None:
             g = np.asarray(part.ext_ldof, np.int64)
@@ -165,8 +167,7 @@ class BakeoffProblem:
     # ---- BilinearForm::Mult (unconstrained L->L), the BK "Kernel" of bench_ceed.cpp:163-190
     def direct_active(self):
         """does mult() write the element-interior rows from the element kernel? (vector_cg.hip: constrained_mult)"""
-        pol = int(os.environ.get("MFEM_AMD_DIRECT", "1"))
-        return bool(self.direct) and (pol == 2 or (pol == 1 and self.D >= 5 and self.nscalar*8 <= (256 << 20)))
+        return bool(self.direct) and int(os.environ.get("MFEM_AMD_DIRECT", "1")) != 0
 
     def l2e(self, x, e0=0, e1=None, y=None):
         """element kernel over the elements [e0, e1) (e0 on a batch boundary of the blocked layout); with y, and where
@@ -209,20 +210,15 @@ class BakeoffProblem:
     def mult(self, x, y):
         """y = A x; in parallel x's ghost entries are refreshed first and y ends with owners
         summed / ghosts zero (P^T A P)."""
-        if self.ex is not None and self.e_split:
-            # P on a second stream while the elements that read no ghost entry are worked on; the ghost
-            # entries of x are written there, the interior elements never read them
-            cur = torch.cuda.current_stream(self.dev)
-            self._ev_x.record(cur)
-            with torch.cuda.stream(self._cstream):
-                self._cstream.wait_event(self._ev_x)
-                self.ex.forward(x.data_ptr(), C.c_void_p(self._cstream.cuda_stream))
-                self._ev_ghosts.record(self._cstream)
-            self.l2e(x, 0, self.e_split, y=y)
-            cur.wait_event(self._ev_ghosts)
-            self.l2e(x, self.e_split, self.ne, y=y)
-            self.e2l(y)
-            self.ex.reverse(y.data_ptr(), self.stream)
+        if self.ex is not None and not self.vdim:
+            # P^T A P in the library (mfem_amd_pa_par_mult): the exchange callbacks are the transport's, the owner -> ghost
+            # exchange runs on a second stream beside the interior elements (op.e_split)
+            if self._comm is None:
+                self._ws = torch.empty(capi.lib.mfem_amd_pcg_workspace_bytes(self.ndofs, 2000), dtype=torch.uint8, device=self.dev)
+                self._comm = self.ex.make_comm(self._ws)
+            rc = capi.lib.mfem_amd_pa_par_mult(C.byref(self.op_free), C.byref(self._comm), _p(x), _p(y), self.stream)
+            if rc != 0:
+                raise capi.MfemAmdError(f"{capi.lib.mfem_amd_last_error().decode()} / {getattr(self.ex, 'error', None)!r}")
             return
         if self.ex is None and not self.vdim:
             capi.call("mfem_amd_pa_apply_L2L", self.kind, self.layout, self.D, self.Q, self.ne, self.nscalar, self.B, self.G,

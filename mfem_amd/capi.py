@@ -34,7 +34,7 @@ class PaOperator(C.Structure):
                 ("masked_gather_map", vp), ("offsets", vp), ("indices", vp),
                 ("ness", i64), ("ess", vp), ("ess_marker", vp), ("yE", vp),
                 ("vdim", cint), ("byvdim", cint), ("pa_comp_stride", i64), ("direct_rows", i64),
-                ("packed_indices", vp)]
+                ("packed_indices", vp), ("e_split", i64)]
 
 
 AR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)

@@ -89,6 +89,9 @@ constexpr int minw_for(int KIND, int D, int PF = 0, int RB = 1, bool VEC = false
 #ifndef MFA_WAVE_SYNC
 #define MFA_WAVE_SYNC 1
 #endif
+#ifndef MFA_SPLIT_O
+#define MFA_SPLIT_O 1
+#endif
 // tuning builds: -DMFA_ONLY_D=<D1D> compiles the specialisations of one D1D only (seconds instead of minutes)
 #ifndef MFA_ONLY_D
 #define MFA_ONLY_D 0
@@ -201,6 +204,20 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
    {
       sB[i] = bg.b[i];
       if (KIND) { sG[i] = bg.g[i]; }
+   }
+   // DIRECT: where the D entries of store-phase row (dz,dy) go in the packed E-vector (common.h: packed_pos) -- first entry,
+   // distance to the last, first of the D-2 middle ones (inner rows: offset of the interior run in the L-vector), packed
+   // into one int per row.  Computed here, where registers are free, and read back from LDS in the store phase: derived
+   // there (or hoisted here by the compiler) the same integers cost the (5,6) kernel its third wave's registers.
+   __shared__ int sTab[DIRECT ? D*D : 1];
+   if (DIRECT && va.ydirect && tz == 0 && t2 < D*D)
+   {
+      constexpr int DI = D - 2;
+      const int rz = t2/D, ry = t2 % D;
+      const bool inner = rz >= 1 && rz <= DI && ry >= 1 && ry <= DI;
+      const int p0 = packed_pos(D, rz, ry, 0), pl = packed_pos(D, rz, ry, D - 1);
+      const int pm = inner ? ((rz - 1)*DI + (ry - 1))*DI : packed_pos(D, rz, ry, 1);
+      sTab[t2] = p0 | ((pl - p0) << 10) | (pm << 20) | (inner ? (1 << 30) : 0);
    }
    constexpr bool WS = MFA_WAVE_SYNC && (64 % QQ == 0) && (ABL == 0 || MFA_ABL(2));
    if (WS) { __syncthreads(); }           // the basis tables are shared by all waves: the only workgroup barrier
@@ -344,11 +361,29 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
       else { dst[0] = Dq[bt*(int64_t)(Q*NBZ*QQ) + tz*QQ + b*Q + a + qz*(NBZ*QQ)]; }
    };
 
+   // the gathered x values go to LDS (region sX)
+   auto stage_x = [&]()
+   {
+#pragma unroll
+      for (int k = 0; k < NXV; k++)
+      {
+         const int i = t2 + k*QQ;
+         if (i < D3) { sX[RB ? (i/D)*DP + i % D : i] = xv[k]; }
+      }
+   };
+   // One batch per workgroup, whole pa_data columns in registers: the x values can be staged between the two halves of the
+   // pa_data requests, so that their registers are free again before the second half is allocated.  It removes the one
+   // spilled x value of the (5,6) kernel (whose reload waits for EVERY outstanding load, vmcnt(0)) -- and still loses there:
+   // the second half of the stream is requested one memory latency later (profiles/r3/split_o_ab.txt, whole apply, two
+   // runs each: p = 3 0.563 vs 0.582, p = 4 0.590 vs 0.605, p = 5 0.570 vs 0.580, p = 6 0.620 vs 0.632).  Only D = 3, with
+   // four short columns per thread, gains (p = 2: 0.560 vs 0.537), and keeps it.
+   constexpr bool SPLIT = MFA_SPLIT_O && D == 3 && !PERSIST && !VEC && PF == 0 && ABL == 0 && KIND == 1;
    {
       const int64_t e = b0*NBZ + tz;
       load_gi(e);
       load_xv(e);
-      if (PF == 0) { load_O(e, b0); }
+      if (SPLIT) { load_O(e, b0, 0, Q/2); stage_x(); load_O(e, b0, Q/2, Q); }
+      else if (PF == 0) { load_O(e, b0); }
       else
       {
 #pragma unroll
@@ -372,12 +407,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
          // staged (below), so only the first gather of a workgroup is waited for
          if (VEC && comp > 0 && va.d_comp_stride) { load_O(e, bt); }
 
-#pragma unroll
-         for (int k = 0; k < NXV; k++)
-         {
-            const int i = t2 + k*QQ;
-            if (i < D3) { sX[RB ? (i/D)*DP + i % D : i] = xv[k]; }
-         }
+         if (!SPLIT) { stage_x(); }
          if (PERSIST) { load_gi(en); }       // next batch's gather indices: in flight from here
          if (VEC && comp + 1 < va.vd) { load_xv(e, comp + 1); }
          phase_sync<WS>();
@@ -743,29 +773,21 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
                   // One store per value, its address chosen per lane by mask arithmetic: the rows of one wave differ in
                   // kind, and a branch would issue both forms of the row one after the other.  (Not `c ? p : q` on the
                   // pointers: hipcc 7.2 turns that back into exec-masked blocks and sinks one of the moves out of its
-                  // block -- lanes of dy = 0 then stored through their neighbour row's address.)
-                  constexpr int DI = D - 2, E0 = 8, F0 = 8 + 12*DI;
-                  // (opaque copies of the row and element indices: everything derived from them is computed here, after
-                  // the z loop, instead of being hoisted above it and held in registers through the kernel's tightest
-                  // phase; the positions are those of packed_pos, written as selects so that no lane branches)
-                  int row, ez;
-                  asm volatile("v_mov_b32 %0, %1" : "=v"(row) : "v"(t2));
+                  // block -- lanes of dy = 0 then stored through their neighbour row's address.)  The row's positions come
+                  // from the table filled at the top of the kernel.
+                  constexpr int DI = D - 2;
+                  const int code = sTab[t2];
+                  const unsigned p0 = code & 1023, dl = (code >> 10) & 1023, pm = (code >> 20) & 1023;
+                  const uint64_t inner = (uint64_t)(-(int64_t)((code >> 30) & 1));
+                  // (an opaque copy of the element's slot: the two base addresses are formed here, after the z loop, instead of
+                  // being hoisted above it)
+                  int ez;
                   asm volatile("v_mov_b32 %0, %1" : "=v"(ez) : "v"(tz));
                   const int64_t eo = bt*NBZ + ez;
-                  const int rz = row/D, ry = row % D, iz = rz - 1, iy = ry - 1;
-                  const int bz = rz ? 1 : 0, by = ry ? 1 : 0;                      // side, where the row is on the boundary
-                  const int mz = -(int)(rz >= 1 && rz <= DI), my = -(int)(ry >= 1 && ry <= DI);   // all ones: inner in z / y
-                  auto sel = [](const int m, const int a, const int b) { return b ^ ((a ^ b) & m); };   // m ? a : b
-                  // first entry (dx = 0), distance to the last (dx = D-1), first of the D-2 middle entries
-                  const int p0 = sel(mz, sel(my, F0 + 4*DI*DI + iz*DI + iy, E0 + 8*DI + by*2*DI + iz),
-                                         sel(my, E0 + 4*DI + bz*2*DI + iy, bz*4 + by*2));
-                  const int dl = sel(mz, sel(my, DI*DI, DI), sel(my, DI, 1));
-                  const int pm = sel(mz, sel(my, (iz*DI + iy)*DI, F0 + 2*DI*DI + (by*DI + iz)*DI),
-                                         sel(my, F0 + (bz*DI + iy)*DI, E0 + (bz*2 + by)*DI));
                   const uint64_t pb = reinterpret_cast<uint64_t>(yE + eo*packed_size(D));
                   const uint64_t pd = reinterpret_cast<uint64_t>(va.ydirect + eo*(DI*DI*DI));
-                  const uint64_t a0 = pb + 8u*(unsigned)p0;
-                  const uint64_t am = (pb ^ ((pb ^ pd) & (uint64_t)(int64_t)(mz & my))) + 8u*(unsigned)pm;
+                  const uint64_t a0 = pb + 8u*p0;
+                  const uint64_t am = (pb ^ ((pb ^ pd) & inner)) + 8u*pm;
 #pragma unroll
                   for (int dx = 0; dx < D; dx++)
                   {

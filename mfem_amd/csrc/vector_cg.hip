@@ -432,6 +432,37 @@ extern "C" int mfem_amd_jacobi_apply(int64_t n, const double *dinv, const double
 // all local dofs: sum_ranks (P w)^T A_L (P w) = w^T P^T A P w.
 static bool pcg_nt(int64_t n);
 
+// The element kernel over the elements [e0, e1) of a scalar space (e0 on a batch boundary of the blocked layout): the
+// tables, pa_data, the (packed) E-vector and the direct rows of that range.
+static int apply_range(const mfem_amd_pa_operator *op, const int *gm, const double *x, double *y, int64_t nd, int64_t nrows,
+                       int64_t e0, int64_t e1, hipStream_t s)
+{
+   if (e1 <= e0) { return 0; }
+   const int D = op->D1D, Q = op->Q1D;
+   const int64_t D3 = (int64_t)D*D*D, NI = (int64_t)(D - 2)*(D - 2)*(D - 2), Q3 = (int64_t)Q*Q*Q;
+   const int64_t pa_off = op->pa_layout ? blocked_size(op->kind, Q, e0) : e0*(op->kind == 2 ? 9 : (op->kind ? 6 : 1))*Q3;
+   return pa_apply_L2E(op->kind, op->pa_layout, D, Q, e1 - e0, op->B, op->G, op->pa_data + pa_off, gm + e0*D3, x,
+                       op->yE + e0*(nd ? D3 - NI : D3), s, nd ? y + nrows + e0*NI : nullptr);
+}
+
+// a second stream and two events per device for the exchange that runs beside the interior elements (created on first use)
+static int overlap_objects(hipStream_t *side, hipEvent_t *ev_x, hipEvent_t *ev_ghosts)
+{
+   static hipStream_t st[64] = {nullptr};
+   static hipEvent_t ea[64] = {nullptr}, eb[64] = {nullptr};
+   int dev = 0;
+   if (int rc = check_hip(hipGetDevice(&dev), "hipGetDevice")) { return rc; }
+   if (dev < 0 || dev >= 64) { set_error("pa operator: device index %d out of range", dev); return 1; }
+   if (!st[dev])
+   {
+      if (int rc = check_hip(hipStreamCreateWithFlags(&st[dev], hipStreamNonBlocking), "hipStreamCreateWithFlags")) { return rc; }
+      if (int rc = check_hip(hipEventCreateWithFlags(&ea[dev], hipEventDisableTiming), "hipEventCreateWithFlags")) { return rc; }
+      if (int rc = check_hip(hipEventCreateWithFlags(&eb[dev], hipEventDisableTiming), "hipEventCreateWithFlags")) { return rc; }
+   }
+   *side = st[dev]; *ev_x = ea[dev]; *ev_ghosts = eb[dev];
+   return 0;
+}
+
 static int constrained_mult(const mfem_amd_pa_operator *op, const mfem_amd_comm *comm,
                             double *x, double *y, const double *w, double *partials, int nb,
                             const int *skip, hipStream_t s)
@@ -461,7 +492,16 @@ static int constrained_mult(const mfem_amd_pa_operator *op, const mfem_amd_comm 
    }
    const int *gm = ess ? op->masked_gather_map : op->gather_map;
    MFA_REQUIRE(gm, "pa operator: %s is NULL", ess ? "masked_gather_map" : "gather_map");
-   if (comm)
+   // With a communicator and the local elements listed interior first (op->e_split of them read no ghost entry of x), the
+   // owner -> ghost exchange runs on a second stream while the element kernel works on those elements; the interface
+   // elements wait for its event.  (The reference overlaps the local copy only, fem/pfespace.cpp:5441.)  The interior range
+   // is launched BEFORE the exchange is called: a transport that blocks the host still finds the device busy.
+   static const bool overlap_ok = !(getenv("MFEM_AMD_OVERLAP") && atoi(getenv("MFEM_AMD_OVERLAP")) == 0);
+   const bool overlap = comm && overlap_ok && op->e_split > 0 && op->e_split < op->ne;
+   MFA_REQUIRE(op->e_split >= 0 && op->e_split <= op->ne, "pa operator: e_split out of range");
+   MFA_REQUIRE(!overlap || !op->pa_layout || op->e_split % nbz_for(op->Q1D) == 0,
+               "pa operator: e_split must be a multiple of the blocked layout's batch (%d elements)", nbz_for(op->Q1D));
+   if (comm && !overlap)
    {
       if (int rc = comm->forward(comm->ctx, x, (void*)s)) { set_error("comm forward exchange failed (%d)", rc); return rc; }
    }
@@ -469,24 +509,32 @@ static int constrained_mult(const mfem_amd_pa_operator *op, const mfem_amd_comm 
    // direct rows, the element-interior rows y[ndofs - direct_rows, ndofs) -- the gated transpose-gather leaves the
    // rest of y untouched.  `skip` is only passed by the solver, whose y is its work vector z (dead after the end: x has
    // had its last update); a caller that wants y preserved after `skip` must not enable direct rows.
-   // Element-interior rows (the last direct_rows ones, mfem_amd_interior_rows) are written by the element kernel itself and
-   // the transpose-gather sums the rows before them -- where that pays (profiles/r2/direct_rows.txt): the direct stores
-   // are short runs (D-2 doubles) that complete each other's cache lines only while y stays in the 256 MiB Infinity
-   // Cache, so not above 3.3e7 dofs; inside the solver loop (w given) only together with the solver's streaming policy
-   // (pcg_nt: with x, r and dinv cached too the element kernel lost 28 us to gain 10 us in the transpose-gather; with them
-   // out of the cache p = 4 gains 0.4 %, p = 6 3.2 %); and not below p = 4, where an element has 1 or 8 interior dofs and
-   // the rows saved do not pay for the second store stream.  MFEM_AMD_DIRECT=0 never, 2 always.
+   // Element-interior rows (the last direct_rows ones, mfem_amd_interior_rows) are written by the element kernel itself, the
+   // rest of the element goes to the packed E-vector, and the transpose-gather sums the rows before them.  With the packed
+   // form this pays wherever the property holds (profiles/r3/direct_policy.txt, C++ drivers on the reference's numbering:
+   // BP3 p = 2 / 3 +4 / +7 %, p = 4..8 +14..21 %, 1e6 dofs +9 %, 1e8 dofs +16 %, BP1 +8..40 %, inside the solver too) --
+   // round 2's holed layout paid at p >= 4 below 3.3e7 dofs only.  MFEM_AMD_DIRECT=0 never (the plain two-kernel form).
    const char *pol = getenv("MFEM_AMD_DIRECT");
    const int policy = pol ? atoi(pol) : 1;
-   const bool pays = policy == 2 || (policy == 1 && op->D1D >= 5 && op->ndofs*(int64_t)sizeof(double) <= ((int64_t)256 << 20) &&
-                                     (!w || pcg_nt(op->ndofs)));
+   const bool pays = policy != 0;
    // (the E-vector is then the packed one, read through op->packed_indices: no direct rows without that table)
    const int64_t nd = (op->direct_rows > 0 && op->packed_indices && op->kind != 2 && pays) ? op->direct_rows : 0;
    MFA_REQUIRE(nd >= 0 && nd <= op->ndofs, "pa operator: direct_rows out of range");
    const int64_t nrows = op->ndofs - nd;
    if (nd && !w) { nb = (int)((nrows + 1023)/1024 > 0 ? (nrows + 1023)/1024 : 1); }
-   if (int rc = pa_apply_L2E(op->kind, op->pa_layout, op->D1D, op->Q1D, op->ne, op->B, op->G, op->pa_data, gm, x, op->yE, s,
-                             nd ? y + nrows : nullptr)) { return rc; }
+   if (overlap)
+   {
+      hipStream_t side; hipEvent_t ev_x, ev_ghosts;
+      if (int rc = overlap_objects(&side, &ev_x, &ev_ghosts)) { return rc; }
+      if (int rc = check_hip(hipEventRecord(ev_x, s), "hipEventRecord")) { return rc; }
+      if (int rc = check_hip(hipStreamWaitEvent(side, ev_x, 0), "hipStreamWaitEvent")) { return rc; }
+      if (int rc = apply_range(op, gm, x, y, nd, nrows, 0, op->e_split, s)) { return rc; }
+      if (int rc = comm->forward(comm->ctx, x, (void*)side)) { set_error("comm forward exchange failed (%d)", rc); return rc; }
+      if (int rc = check_hip(hipEventRecord(ev_ghosts, side), "hipEventRecord")) { return rc; }
+      if (int rc = check_hip(hipStreamWaitEvent(s, ev_ghosts, 0), "hipStreamWaitEvent")) { return rc; }
+      if (int rc = apply_range(op, gm, x, y, nd, nrows, op->e_split, op->ne, s)) { return rc; }
+   }
+   else if (int rc = apply_range(op, gm, x, y, nd, nrows, 0, op->ne, s)) { return rc; }
    if (int rc = scatter_dot(nrows, op->offsets, nd ? op->packed_indices : op->indices, op->yE, y, ess ? op->ess_marker : nullptr,
                             x, w, partials, nb, skip, s, nd)) { return rc; }
    if (comm)

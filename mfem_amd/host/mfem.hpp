@@ -1199,6 +1199,7 @@ class ParMesh : public Mesh
 {
    MPI_Comm comm; int rank, nranks;
    Mesh serial; std::vector<int> partition, local_elems;
+   int n_interior = 0;
    void BuildLocal();
 public:
    /// partitioning: rank of every element, or NULL = contiguous chunks of the element order (METIS, the
@@ -1212,6 +1213,9 @@ public:
    void UniformRefinement(int ref_algo = 0);
    const Mesh &SerialMesh() const { return serial; }
    const std::vector<int> &LocalElements() const { return local_elems; }
+   /// the local elements are listed interior first: the first InteriorElements() of them touch no vertex of another rank's
+   /// elements, so nothing they read comes through the shared-dof exchange (it can run beside them)
+   int InteriorElements() const { return n_interior; }
    const std::vector<int> &Partitioning() const { return partition; }
 };
 
@@ -1233,8 +1237,8 @@ public:
    ~ParFiniteElementSpace();
    ParMesh *GetParMesh() const { return pmesh; }
    MPI_Comm GetComm() const { return pmesh->GetComm(); }
-   HYPRE_BigInt GlobalTrueVSize() const { return gfes->GetNDofs(); }
-   HYPRE_BigInt GlobalVSize() const { return gfes->GetNDofs(); }
+   HYPRE_BigInt GlobalTrueVSize() const { return gfes->GetVSize(); }
+   HYPRE_BigInt GlobalVSize() const { return gfes->GetVSize(); }
    int GetTrueVSize() const { return GetVSize(); }
    int GetNOwned() const { return n_owned; }
    const Array<int> &LocalToGlobal() const { return l2g; }
@@ -1275,6 +1279,7 @@ class ParPAOperator : public Operator
    mutable mfem_amd_pa_operator cop;
    Array<int> ess; Array<unsigned char> marker; Array<int> masked_gather;
    void RefreshOperator() const;
+   void SetSplit() const;
    friend class CGSolver;
 public:
    ParPAOperator(const PABilinearFormExtension &ext, const ParFiniteElementSpace &pfes, const Array<int> &ess_tdof_list);

@@ -63,7 +63,26 @@ void ParMesh::BuildLocal()
    Mesh loc;
    local_elems.clear();
    const int ne = serial.GetNE();
-   for (int e = 0; e < ne; e++) { if (partition[(size_t)e] == rank) { local_elems.push_back(e); } }
+   // interior elements first (stable within each class): an element is on the interface when one of its vertices
+   // also belongs to an element of another rank -- every shared edge, face and dof lies on such a vertex
+   {
+      std::vector<char> foreign((size_t)serial.GetNV(), 0);
+      for (int e = 0; e < ne; e++)
+      {
+         if (partition[(size_t)e] == rank) { continue; }
+         for (int k = 0; k < 8; k++) { foreign[(size_t)serial.elements[(size_t)8*e + k]] = 1; }
+      }
+      std::vector<int> iface;
+      for (int e = 0; e < ne; e++)
+      {
+         if (partition[(size_t)e] != rank) { continue; }
+         bool on = false;
+         for (int k = 0; k < 8; k++) { on = on || foreign[(size_t)serial.elements[(size_t)8*e + k]]; }
+         (on ? iface : local_elems).push_back(e);
+      }
+      n_interior = (int)local_elems.size();
+      local_elems.insert(local_elems.end(), iface.begin(), iface.end());
+   }
    std::vector<int> vmap((size_t)serial.GetNV(), -1);
    for (int e : local_elems) { for (int k = 0; k < 8; k++) { vmap[(size_t)serial.elements[(size_t)8*e + k]] = 0; } }
    int nv = 0;
@@ -120,7 +139,6 @@ void ParMesh::UniformRefinement(int ref_algo)
 ParFiniteElementSpace::ParFiniteElementSpace(ParMesh *pm, const FiniteElementCollection *fec_, int vdim_, int ordering_)
    : FiniteElementSpace(pm, fec_, vdim_, ordering_), pmesh(pm)
 {
-   MFEM_VERIFY(vdim_ == 1, "mfem_amd: parallel spaces are built for scalar fields (vdim = 1)");
    std::memset(&cb, 0, sizeof cb);
    gfes = new FiniteElementSpace(const_cast<Mesh*>(&pm->SerialMesh()), fec_, vdim_, ordering_);
    BuildSharedTables();
@@ -170,20 +188,23 @@ void ParFiniteElementSpace::BuildSharedTables()
    for (int i = 0; i < nl; i++)
    {
       const int o = owner[(size_t)lg[i]];
-      if (o == me) { n_owned++; }
+      if (o == me) { n_owned += GetVDim(); }
       else { lo.emplace_back(o, lg[i]); }
    }
    std::sort(lo.begin(), lo.end());
+   // vector spaces (fem/pfespace.cpp:5266-5345 builds its tables on vdofs): every shared dof carries its vd components,
+   // next to each other in the messages, at the vdofs the space's ordering gives them
+   const int vd = GetVDim();
    auto flatten = [&](const std::vector<std::pair<int, int>> &prs, std::vector<int> &ranks, std::vector<int> &sizes, Array<int> &ids)
    {
       ranks.clear(); sizes.clear();
-      ids.SetSize((int)prs.size());
+      ids.SetSize((int)prs.size()*vd);
       int *p = ids.HostWrite();
       for (size_t k = 0; k < prs.size(); k++)
       {
          if (ranks.empty() || ranks.back() != prs[k].first) { ranks.push_back(prs[k].first); sizes.push_back(0); }
-         sizes.back()++;
-         p[k] = g2l[(size_t)prs[k].second];
+         sizes.back() += vd;
+         for (int c = 0; c < vd; c++) { p[k*vd + c] = DofToVDof(g2l[(size_t)prs[k].second], c); }
       }
    };
    flatten(up, up_ranks, up_sizes, shr_ltdof);
@@ -224,11 +245,16 @@ void ParFiniteElementSpace::GetEssentialTrueDofs(const Array<int> &bdr_attr_is_e
    for (int i = 0; i < gmarker.Size() && i < bdr_attr_is_ess.Size(); i++) { gmarker[i] = bdr_attr_is_ess[i]; }
    Array<int> gess;
    if (gmarker.Size()) { gfes->GetEssentialVDofs(gmarker, gess, component); }
-   const int nl = GetNDofs();
-   int n = 0;
-   for (int i = 0; i < nl; i++) { if (gess.Size() && gess[l2g[i]]) { n++; } }
-   ess_tdof_list.SetSize(n);
-   for (int i = 0, k = 0; i < nl; i++) { if (gess.Size() && gess[l2g[i]]) { ess_tdof_list[k++] = i; } }
+   // local vdof (i, c) <-> global vdof (l2g[i], c), each in its own space's ordering; the list ascends in local vdofs
+   const int nl = GetNDofs(), vd = GetVDim();
+   std::vector<int> list;
+   for (int i = 0; gess.Size() && i < nl; i++)
+   {
+      for (int c = 0; c < vd; c++) { if (gess[gfes->DofToVDof(l2g[i], c)]) { list.push_back(DofToVDof(i, c)); } }
+   }
+   std::sort(list.begin(), list.end());
+   ess_tdof_list.SetSize((int)list.size());
+   for (size_t k = 0; k < list.size(); k++) { ess_tdof_list[(int)k] = list[k]; }
 }
 
 void ParFiniteElementSpace::Forward(Vector &v) const
@@ -240,6 +266,15 @@ void ParFiniteElementSpace::Reverse(Vector &v) const
 {
    MFEM_VERIFY(v.Size() == GetVSize(), "ParFiniteElementSpace::Reverse: wrong vector size");
    if (cb.reverse(cb.ctx, v.ReadWrite(), nullptr) != 0) { MFEM_ABORT("mfem_amd: shared-dof exchange (P^T) failed: " << mfem_amd_comm_last_error()); }
+}
+
+// the forward exchange runs beside the interior elements (mfem_amd_pa_operator::e_split): whole batches of the blocked layout
+static int64_t interior_split(const mfem_amd_pa_operator &op, int n_interior)
+{
+   if (op.vdim > 0 || op.kind == 2) { return 0; }
+   const int64_t per = (op.kind ? 6 : 1)*(int64_t)op.Q1D*op.Q1D*op.Q1D;
+   const int64_t nbz = op.pa_layout ? mfem_amd_pa_data_size(op.kind, 1, op.Q1D, 1)/per : 1;
+   return (n_interior/nbz)*nbz;
 }
 
 // ---- ParPAOperator --------------------------------------------------------------------------------
@@ -254,7 +289,7 @@ ParPAOperator::ParPAOperator(const PABilinearFormExtension &ext, const ParFinite
    const Array<int> &gh = pf.GhostDofs();
    for (int i = 0; i < gh.Size(); i++) { if (m[gh[i]]) { m[gh[i]] = 2; } }       // essential ghost copy: y = 0
    const int ness = ess.Size();
-   if (ness)
+   if (ness && cop.vdim == 0)                  // (vector spaces apply the vdof marker in the gather instead)
    {
       const ElementRestriction *R = ext.GetElementRestriction();
       masked_gather.SetSize(R->GatherMap().Size());
@@ -262,14 +297,17 @@ ParPAOperator::ParPAOperator(const PABilinearFormExtension &ext, const ParFinite
       cop.masked_gather_map = masked_gather.Read();
    }
    cop.ness = ness; cop.ess = ness ? ess.Read() : nullptr; cop.ess_marker = marker.Read();
+   SetSplit();
 }
+void ParPAOperator::SetSplit() const { cop.e_split = interior_split(cop, pfes->GetParMesh()->InteriorElements()); }
 // as ConstrainedOperator::RefreshOperator (fem.cpp): the form's buffers may have moved since construction
 void ParPAOperator::RefreshOperator() const
 {
    const int64_t ness = cop.ness;
    MFEM_VERIFY(pa->FillOperator(cop), "mfem_amd: the form behind the parallel operator lost its partial assembly");
    cop.ness = ness; cop.ess = ness ? ess.Read() : nullptr; cop.ess_marker = marker.Read();
-   if (ness) { cop.masked_gather_map = masked_gather.Read(); }
+   if (ness && cop.vdim == 0) { cop.masked_gather_map = masked_gather.Read(); }
+   SetSplit();
 }
 void ParPAOperator::Mult(const Vector &x, Vector &y) const
 {
@@ -282,6 +320,16 @@ void ParPAOperator::Mult(const Vector &x, Vector &y) const
 void ParBilinearForm::Mult(const Vector &x, Vector &y) const
 {
    Vector xx(x);
+   const PABilinearFormExtension *ext = GetPAExtension();
+   mfem_amd_pa_operator op;
+   if (ext && ext->FillOperator(op) && op.vdim == 0 && xx.Read() != y.Read())
+   {
+      // the unconstrained P^T A P in one library call: the owner -> ghost exchange beside the interior elements
+      op.e_split = interior_split(op, pfes->GetParMesh()->InteriorElements());
+      y.SetSize(xx.Size());
+      MFEM_AMD_CALL(mfem_amd_pa_par_mult(&op, pfes->Comm(), xx.ReadWrite(), y.Write(), nullptr));
+      return;
+   }
    pfes->Forward(xx);
    BilinearForm::Mult(xx, y);
    pfes->Reverse(y);

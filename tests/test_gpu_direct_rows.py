@@ -113,8 +113,8 @@ def test_interior_last_numbering_matches_lexicographic(gh, problem, p, n, monkey
     b = torch.rand(lex.ndofs, dtype=torch.float64, generator=g).to(dev)
     bi = torch.empty_like(b); bi[il.perm] = b
     bi[il.ess.long()] = 0.0
-    # (by default the solver loop keeps the E-vector route -- vector_cg.hip: constrained_mult; MFEM_AMD_DIRECT=2 makes it
-    # write the interior rows directly and take their part of (d, A d) in the transpose-gather kernel)
+    # (the default policy writes the interior rows directly wherever the numbering allows, inside the solver too, and takes
+    # their part of (d, A d) in the transpose-gather kernel -- vector_cg.hip: constrained_mult; MFEM_AMD_DIRECT=0 never)
     monkeypatch.delenv("MFEM_AMD_DIRECT")
     yd = torch.full_like(xl, float("nan"))
     il.mult(xi, yd)                                  # default policy
@@ -124,7 +124,11 @@ def test_interior_last_numbering_matches_lexicographic(gh, problem, p, n, monkey
     monkeypatch.setenv("MFEM_AMD_DIRECT", "2")
     X1, r1, h1 = il.pcg(bi, 1e-8, max_iter=400, check_every=3, want_hist=True)
     X0, r0, h0 = il0.pcg(bi, 1e-8, max_iter=400, check_every=3, want_hist=True)
-    assert torch.equal(X3, X0) and np.array_equal(h3, h0)
+    assert torch.equal(X3, X1) and np.array_equal(h3, h1)
+    monkeypatch.setenv("MFEM_AMD_DIRECT", "0")
+    X4, r4, h4 = il.pcg(bi, 1e-8, max_iter=400, check_every=3, want_hist=True)
+    assert torch.equal(X4, X0) and np.array_equal(h4, h0)          # the plain form on the same numbering: same bits
+    monkeypatch.setenv("MFEM_AMD_DIRECT", "2")
     assert (r1.iterations, r1.converged) == (r0.iterations, r0.converged) and r1.converged
     assert np.max(np.abs(h1 - h0)/h0[0]) < 1e-12
     assert torch.max(torch.abs(X1 - X0)).item() <= 1e-10*torch.max(torch.abs(X0)).item()
