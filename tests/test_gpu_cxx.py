@@ -219,7 +219,7 @@ def test_cxx_mult_transpose_of_nonsymmetric_form_aborts(tmp_path):
 
 
 # ---- the parallel C++ layer: ex1p on ParMesh / ParFiniteElementSpace / ParBilinearForm / CGSolver(MPI_COMM_WORLD) ----
-def _run_ex1p(nranks, args, transport):
+def _run_ex1p(nranks, args, transport, exe="ex1p"):
     """one process per rank, launched the way any launcher would: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* in the
     environment.  Several ranks on the one GPU of the test box use the host-staged TCP transport."""
     import os
@@ -228,7 +228,7 @@ def _run_ex1p(nranks, args, transport):
     for r in range(nranks):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), MFEM_AMD_TRANSPORT=transport)
-        procs.append(subprocess.Popen([str(BIN / "ex1p")] + [str(a) for a in args], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+        procs.append(subprocess.Popen([str(BIN / exe)] + [str(a) for a in args], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                                       text=True, env=env, cwd=str(ROOT)))
     outs = [p.communicate(timeout=280) for p in procs]
     for p, (so, se) in zip(procs, outs):
@@ -298,3 +298,24 @@ def test_cxx_bench_ceed_at_full_size():
     assert np.isfinite(k["norm_Ax"]) and k["norm_Ax"] > 0
     assert c["sym_err"] < 1e-12 and c["const_err"] < 1e-12, c
     assert pr["iterations"] == 10 and pr["nom0"] > 0 and pr["nom_last"] > 0 and np.isfinite(pr["nom_last"]) and np.isfinite(pr["norm_X"])
+
+
+@pytest.mark.parametrize("bp,p,n", [(4, 2, 6), (2, 3, 4), (6, 3, 4), (3, 4, 4)])
+def test_cxx_parallel_bakeoff_matches_serial(bp, p, n):
+    """examples/bench_ceed_p.cpp (ParMesh / ParFiniteElementSpace / ParBilinearForm / CGSolver(MPI_Comm)) with 1 rank on
+    RCCL and 2, 3 ranks over the TCP transport against the serial bench_ceed on the same mesh: vector spaces (vdim = 3,
+    byVDIM) in the parallel layer -- same unknown count, same Jacobi-PCG iteration count at a tolerance outside the rounding
+    floor (rel 1e-8), |X| to 1e-9, |A X| (the unconstrained P^T A P) to 1e-9 between rank counts."""
+    ser = [json.loads(ln) for ln in run([BIN / "bench_ceed", "-bp", bp, "-p", p, "-n", n, "-reps", 2, "-rtol", 1e-8]).splitlines()
+           if ln.startswith("{")]
+    sp = [d for d in ser if d["phase"] == "problem"][0]
+    res = {}
+    for nr, tr in ((1, "rccl"), (2, "tcp"), (3, "tcp")):
+        txt = _run_ex1p(nr, ["-bp", bp, "-p", p, "-n", n, "-reps", 2, "-rtol", 1e-8], tr, exe="bench_ceed_p")
+        d = [json.loads(ln) for ln in txt.splitlines() if ln.startswith("{")][0]
+        assert d["ranks"] == nr and d["dofs"] == sp["dofs"]
+        assert d["iterations"] == sp["iterations"] and d["converged"] == 1, (nr, d["iterations"], sp["iterations"])
+        assert abs(d["norm_X"] - sp["norm_X"]) <= 1e-9*sp["norm_X"], (nr, d["norm_X"], sp["norm_X"])
+        res[nr] = d
+    for nr in (2, 3):
+        assert abs(res[nr]["norm_AX"] - res[1]["norm_AX"]) <= 1e-9*res[1]["norm_AX"]
