@@ -14,7 +14,10 @@
  * MASTER_ADDR:MASTER_PORT(+offset) (the environment torch.distributed.run / any launcher sets), which carries
  * the RCCL unique id and the few host-side integers of the set-up.  Transport MFEM_AMD_TRANSPORT_TCP moves the
  * messages themselves over those sockets, staged through the host: for tests with several ranks on ONE GPU
- * (RCCL refuses two ranks on one device) and for debugging -- never for measurements.
+ * (RCCL refuses two ranks on one device) and for debugging -- never for measurements.  The rendezvous listens on
+ * every interface, unauthenticated, for the 120 s of the bootstrap: it is meant for the ranks of ONE host (or one
+ * trusted cluster network), as torch.distributed's own store is; a bootstrap that fails releases every socket it
+ * opened and says which step failed (mfem_amd_comm_last_error).
  */
 #ifndef MFEM_AMD_COMM_H
 #define MFEM_AMD_COMM_H

@@ -191,6 +191,7 @@ extern "C" int mfem_amd_world_create(int rank, int size, const char *addr, int p
       transport = (t && strcmp(t, "tcp") == 0) ? MFEM_AMD_TRANSPORT_TCP : MFEM_AMD_TRANSPORT_RCCL;
    }
    if (size < 1 || rank < 0 || rank >= size) { return fail("world_create: bad rank %d / size %d", rank, size); }
+   if (size > 1 && (port + port_offset < 1 || port + port_offset > 65535)) { return fail("world_create: port %d + offset %d is not a TCP port", port, port_offset); }
    mfem_amd_world *w = new mfem_amd_world;
    w->rank = rank; w->size = size; w->transport = transport;
    w->fds.assign((size_t)size, -1);
@@ -202,44 +203,44 @@ extern "C" int mfem_amd_world_create(int rank, int size, const char *addr, int p
       if (rank == 0)
       {
          int lport = 0;
-         if (listen_on(p0, &w->listen_fd, &lport)) { delete w; return 1; }
+         if (listen_on(p0, &w->listen_fd, &lport)) { mfem_amd_world_destroy(w); return 1; }
          // every other rank connects and says who it is and where IT listens (TCP transport: pairwise sockets)
          std::vector<uint32_t> peer_addr((size_t)size, 0), peer_port((size_t)size, 0);
          for (int k = 1; k < size; k++)
          {
             sockaddr_in pa;
             const int fd = accept_peer(w->listen_fd, &pa, 120);
-            if (fd < 0) { delete w; return fail("accept (%d of %d ranks have not connected within 120 s): %s", size - k, size, strerror(errno)); }
+            if (fd < 0) { mfem_amd_world_destroy(w); return fail("accept (%d of %d ranks have not connected within 120 s): %s", size - k, size, strerror(errno)); }
             tune(fd);
             int32_t hello[2];
-            if (recv_all(fd, hello, sizeof hello)) { delete w; return 1; }
-            if (hello[0] < 1 || hello[0] >= size || w->fds[(size_t)hello[0]] >= 0) { delete w; return fail("bootstrap: bad or duplicate rank %d", hello[0]); }
+            if (recv_all(fd, hello, sizeof hello)) { mfem_amd_world_destroy(w); return 1; }
+            if (hello[0] < 1 || hello[0] >= size || w->fds[(size_t)hello[0]] >= 0) { mfem_amd_world_destroy(w); return fail("bootstrap: bad or duplicate rank %d", hello[0]); }
             w->fds[(size_t)hello[0]] = fd;
             peer_addr[(size_t)hello[0]] = pa.sin_addr.s_addr; peer_port[(size_t)hello[0]] = (uint32_t)hello[1];
          }
          if (transport == MFEM_AMD_TRANSPORT_RCCL)
          {
             ncclResult_t r = ncclGetUniqueId(&id);
-            if (r != ncclSuccess) { delete w; return fail("ncclGetUniqueId: %s", ncclGetErrorString(r)); }
+            if (r != ncclSuccess) { mfem_amd_world_destroy(w); return fail("ncclGetUniqueId: %s", ncclGetErrorString(r)); }
          }
          for (int k = 1; k < size; k++)
          {
             if (send_all(w->fds[(size_t)k], &id, sizeof id) || send_all(w->fds[(size_t)k], peer_addr.data(), sizeof(uint32_t)*(size_t)size) ||
-                send_all(w->fds[(size_t)k], peer_port.data(), sizeof(uint32_t)*(size_t)size)) { delete w; return 1; }
+                send_all(w->fds[(size_t)k], peer_port.data(), sizeof(uint32_t)*(size_t)size)) { mfem_amd_world_destroy(w); return 1; }
          }
       }
       else
       {
          uint32_t root_addr = 0;
-         if (resolve(addr, &root_addr)) { delete w; return 1; }
+         if (resolve(addr, &root_addr)) { mfem_amd_world_destroy(w); return 1; }
          int lport = 0;
-         if (listen_on(0, &w->listen_fd, &lport)) { delete w; return 1; }
-         if (connect_to(root_addr, p0, &w->root_fd)) { delete w; return 1; }
+         if (listen_on(0, &w->listen_fd, &lport)) { mfem_amd_world_destroy(w); return 1; }
+         if (connect_to(root_addr, p0, &w->root_fd)) { mfem_amd_world_destroy(w); return 1; }
          int32_t hello[2] = {rank, lport};
          std::vector<uint32_t> peer_addr((size_t)size), peer_port((size_t)size);
          if (send_all(w->root_fd, hello, sizeof hello) || recv_all(w->root_fd, &id, sizeof id) ||
              recv_all(w->root_fd, peer_addr.data(), sizeof(uint32_t)*(size_t)size) ||
-             recv_all(w->root_fd, peer_port.data(), sizeof(uint32_t)*(size_t)size)) { delete w; return 1; }
+             recv_all(w->root_fd, peer_port.data(), sizeof(uint32_t)*(size_t)size)) { mfem_amd_world_destroy(w); return 1; }
          w->fds[0] = w->root_fd;
          if (transport == MFEM_AMD_TRANSPORT_TCP)
          {
@@ -247,19 +248,19 @@ extern "C" int mfem_amd_world_create(int rank, int size, const char *addr, int p
             for (int j = 1; j < rank; j++)
             {
                int fd = -1;
-               if (connect_to(peer_addr[(size_t)j], (int)peer_port[(size_t)j], &fd)) { delete w; return 1; }
+               if (connect_to(peer_addr[(size_t)j], (int)peer_port[(size_t)j], &fd)) { mfem_amd_world_destroy(w); return 1; }
                int32_t me = rank;
-               if (send_all(fd, &me, sizeof me)) { delete w; return 1; }
+               if (send_all(fd, &me, sizeof me)) { mfem_amd_world_destroy(w); return 1; }
                w->fds[(size_t)j] = fd;
             }
             for (int k = rank + 1; k < size; k++)
             {
                const int fd = accept_peer(w->listen_fd, nullptr, 120);
-               if (fd < 0) { delete w; return fail("accept (peer ranks above %d): %s", rank, strerror(errno)); }
+               if (fd < 0) { mfem_amd_world_destroy(w); return fail("accept (peer ranks above %d): %s", rank, strerror(errno)); }
                tune(fd);
                int32_t who = -1;
-               if (recv_all(fd, &who, sizeof who)) { delete w; return 1; }
-               if (who <= rank || who >= size || w->fds[(size_t)who] >= 0) { delete w; return fail("bootstrap: bad peer rank %d", who); }
+               if (recv_all(fd, &who, sizeof who)) { mfem_amd_world_destroy(w); return 1; }
+               if (who <= rank || who >= size || w->fds[(size_t)who] >= 0) { mfem_amd_world_destroy(w); return fail("bootstrap: bad peer rank %d", who); }
                w->fds[(size_t)who] = fd;
             }
          }
@@ -268,12 +269,12 @@ extern "C" int mfem_amd_world_create(int rank, int size, const char *addr, int p
    else if (transport == MFEM_AMD_TRANSPORT_RCCL)
    {
       ncclResult_t r = ncclGetUniqueId(&id);
-      if (r != ncclSuccess) { delete w; return fail("ncclGetUniqueId: %s", ncclGetErrorString(r)); }
+      if (r != ncclSuccess) { mfem_amd_world_destroy(w); return fail("ncclGetUniqueId: %s", ncclGetErrorString(r)); }
    }
    if (transport == MFEM_AMD_TRANSPORT_RCCL)
    {
       ncclResult_t r = ncclCommInitRank(&w->nccl, size, id, rank);
-      if (r != ncclSuccess) { delete w; return fail("ncclCommInitRank(rank %d of %d): %s", rank, size, ncclGetErrorString(r)); }
+      if (r != ncclSuccess) { mfem_amd_world_destroy(w); return fail("ncclCommInitRank(rank %d of %d): %s", rank, size, ncclGetErrorString(r)); }
    }
    *world = w;
    return 0;
@@ -314,6 +315,7 @@ extern "C" int mfem_amd_world_destroy(mfem_amd_world *w)
    if (!w) { return 0; }
    if (w->nccl) { ncclCommDestroy(w->nccl); }
    for (int fd : w->fds) { if (fd >= 0) { ::close(fd); } }
+   if (w->root_fd >= 0 && (w->fds.empty() || w->fds[0] != w->root_fd)) { ::close(w->root_fd); }   // a bootstrap that failed half way
    if (w->listen_fd >= 0) { ::close(w->listen_fd); }
    delete w;
    return 0;

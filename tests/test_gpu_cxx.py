@@ -257,7 +257,10 @@ def test_ex1p_cxx_ranks_match_serial_ex1(mesh, order):
     h1 = res[1][1]
     for nr in (2, 3):
         h = res[nr][1]
-        assert abs(len(h) - len(h1)) <= 1
+        # ex1p's own tolerance (rel 1e-12 on sqrt((B r, r))) is decided inside the rounding floor; the count is compared where
+        # it is decided outside it -- the first iteration below ex1's threshold (1e-12 (B r, r)_0) is the same on any rank count
+        first = lambda hh: int(np.argmax(np.asarray(hh) <= 1e-12*hh[0]))
+        assert first(h) == first(h1) > 0, (nr, first(h), first(h1))
         k = min(len(h), len(h1))
         big = h1[:k] > 1e-10*h1[0]
         assert np.all(np.abs(h[:k][big] - h1[:k][big]) <= 1e-5*h1[:k][big]), nr      # 6 printed digits

@@ -3,6 +3,9 @@
 AssemblyLevel::PARTIAL, vdim = 3, byVDIM as tests/benchmarks/bench_ceed.cpp:47 and byNODES).
 Bars: data movement bit-exact, operator action 1e-12 relative, identical CG iteration counts."""
 import ctypes as C
+import json
+import os
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -11,6 +14,8 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 from test_oracle_vector import CASES, load_vec, rel          # noqa: E402
+
+ROOT = Path(__file__).resolve().parent.parent
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -72,7 +77,20 @@ def test_vector_path_matches_reference(name):
         assert rel(host(X), c["X"]) < 1e-9
         X2, res2 = zeros(n), capi.PcgResult()
         capi.call("mfem_amd_pcg_pa", C.byref(op), None, ptr(b_d), ptr(X2), 1e-12, 0.0, 32, 4, ptr(ws), C.byref(res2), None, None)
-        # rel tol 1e-12 on sqrt((r,r)) is a 1e-24 reduction: where CG converges before the 32-iteration cap the
-        # last decision sits in the dot products' rounding (the reference sums sequentially): +-1
-        assert abs(res2.iterations - c["cg32_iters"]) <= (1 if c["cg32_iters"] < 32 else 0)
+        # rel tol 1e-12 on sqrt((r,r)) is a 1e-24 reduction: where CG converges before the 32-iteration cap the last
+        # decision sits in the dot products' rounding (the reference sums sequentially).  The count is asserted EXACTLY:
+        # the reference's where the cap decides, else the one recorded for this library beside the reference's
+        # (tests/golden/vec/cg32_device_counts.json, written by this test under MFEM_AMD_RECORD=1 on the GPU box)
+        rec_file = ROOT / "tests" / "golden" / "vec" / "cg32_device_counts.json"
+        rec = json.loads(rec_file.read_text()) if rec_file.exists() else {}
+        key = f"{name}/layout{layout}"
+        if os.environ.get("MFEM_AMD_RECORD") == "1":
+            rec[key] = {"device": int(res2.iterations), "reference": int(c["cg32_iters"])}
+            rec_file.write_text(json.dumps(rec, indent=1, sort_keys=True) + "\n")
+        if c["cg32_iters"] == 32:
+            assert res2.iterations == 32
+        else:
+            assert key in rec, f"no recorded count for {key}: run once with MFEM_AMD_RECORD=1"
+            assert res2.iterations == rec[key]["device"] and rec[key]["reference"] == c["cg32_iters"], (res2.iterations, rec[key])
+            assert abs(rec[key]["device"] - rec[key]["reference"]) <= 1
         assert rel(host(X2), c["X_cg32"]) < 1e-9
