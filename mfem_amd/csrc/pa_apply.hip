@@ -189,7 +189,14 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
    const int SCHED = PERSIST ? sched : 1;
    const int64_t G_ = gridDim.x;
    // one batch per workgroup with sched == 2: workgroups b, b+8, ... (one XCD, one L2) take consecutive batches
-   const int64_t L = (PERSIST ? SCHED != 0 : sched != 2) ? (int64_t)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+   // sched >= 4 (one batch per workgroup): runs of `sched` consecutive batches go to one XCD -- workgroups w, w+8, ... of
+   // a window of 8*sched -- so that neighbouring batches share an L2 while every XCD stays in the same window of memory
+   int64_t L = (PERSIST ? SCHED != 0 : sched != 2) ? (int64_t)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+   if (!PERSIST && sched >= 4)
+   {
+      const int64_t per = 8*(int64_t)sched, bid = blockIdx.x;
+      if (bid < (G_/per)*per) { L = ((bid/per)*8 + (bid & 7))*sched + ((bid >> 3) % sched); }
+   }
    const int64_t b0 = SCHED ? L : (L*nbatches)/G_;
    const int64_t b1 = SCHED ? nbatches : ((L + 1)*nbatches)/G_;
    const int64_t bstep = SCHED ? G_ : 1;
@@ -1195,7 +1202,9 @@ static int launch_apply(int64_t ne, const double *B, const double *G, const doub
    if (mode == 0)
    {
       MFA_REQUIRE(nb < (int64_t)2147483647, "pa_apply: too many workgroups (%lld)", (long long)nb);
-      static const int xcd = (getenv("MFEM_AMD_APPLY_XCD") && atoi(getenv("MFEM_AMD_APPLY_XCD"))) ? 2 : 1;
+      // tuning aid: MFEM_AMD_APPLY_XCD=1 XCD-contiguous batches, >= 4 runs of that many batches per XCD (profiles/r3/xcd_runs.txt)
+      static const int xcd_env = getenv("MFEM_AMD_APPLY_XCD") ? atoi(getenv("MFEM_AMD_APPLY_XCD")) : 0;
+      static const int xcd = xcd_env >= 4 ? xcd_env : xcd_env ? 2 : 1;
       kern1<<<dim3((unsigned)nb), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, xcd, bg, Dq, x, gmap, yE, va);
    }
    else
