@@ -316,6 +316,12 @@ typedef struct mfem_amd_pa_operator
                                 part of the element kernel runs while the owner -> ghost exchange is in flight on a second
                                 stream; a multiple of the blocked layout's batch (mfem_amd_pa_data_size(kind, 1, Q1D, 1) /
                                 (C*Q1D^3) elements).  0: the exchange first, then all elements */
+   int reverse_overlap;      /* partitioned runs (scalar spaces): 1 = ghost_rows / n_ghost_rows below are set and the ghost -> owner
+                                exchange may run beside the transpose-gather; 0: it follows the transpose-gather */
+   const int *ghost_rows;    /* the n_ghost_rows local L-dofs that other ranks own (the exchange's ext_ldof list; device; may be */
+   int64_t n_ghost_rows;     /* empty).  With reverse_overlap and a communicator that offers reverse_begin / reverse_end, those
+                                rows are summed first and travel to their owners on a second stream while the transpose-gather
+                                sums all rows (the reference, fem/pfespace.cpp:5503-5539, has no such overlap) */
 } mfem_amd_pa_operator;
 
 /* Element-interior dofs belong to one element, so their rows of G^T are single entries: when they are the LAST
@@ -417,6 +423,11 @@ int mfem_amd_shared_accumulate(int64_t nuniq, const int *unq_ldof, const int *un
  *   reverse(v): P^T  -- owner entries += ghost entries of the sharing ranks, in fixed
  *                       neighbour order; then the local ghost entries := 0 (:5503-5539)
  *   allreduce_sum(buf, n): in-place sum over ranks of n device doubles.
+ *   reverse_begin(v) / reverse_end(v): optional (NULL: not offered), the two halves of reverse(v) for callers that
+ *                       overlap them with other work: begin packs the ghost entries of v and moves them to their
+ *                       owners' receive buffers (v is only read); end adds what arrived to the owner entries in the
+ *                       same fixed order and zeroes the ghosts.  begin; end on one stream == reverse.  The two may be
+ *                       handed DIFFERENT streams; the caller orders end after begin with an event.
  * Return 0 on success. */
 typedef struct mfem_amd_comm
 {
@@ -424,6 +435,8 @@ typedef struct mfem_amd_comm
    int (*allreduce_sum)(void *ctx, double *dev_buf, int n, void *stream);
    int (*forward)(void *ctx, double *v, void *stream);
    int (*reverse)(void *ctx, double *v, void *stream);
+   int (*reverse_begin)(void *ctx, const double *v, void *stream);
+   int (*reverse_end)(void *ctx, double *v, void *stream);
 } mfem_amd_comm;
 
 /* RAPOperator(P, ConstrainedOperator(A), P)::Mult (linalg/operator.cpp:433,586-646):

@@ -147,15 +147,19 @@ class BakeoffProblem:
             self.op.packed_indices = self.pind.data_ptr()
         # the library overlaps the owner -> ghost exchange with the first e_split elements (include/mfem_amd.h)
         self.op.e_split = 0 if self.vdim else self.e_split
-        # BilinearForm::Mult is the unconstrained operator: the same tables without the essential list
-        self.op_free = capi.PaOperator.from_buffer_copy(self.op)
-        self.op_free.ness, self.op_free.ess, self.op_free.ess_marker, self.op_free.masked_gather_map = 0, None, None, None
         self.ghost = None
         if part is not None:
             g = np.asarray(part.ext_ldof, np.int64)
             if self.vdim:
                 g = (g[:, None]*vd + np.arange(vd)[None, :]).reshape(-1)
             self.ghost = t(g.astype(np.int32))
+            # ... and the ghost -> owner exchange with the transpose-gather: the ghost rows are summed first (include/mfem_amd.h)
+            if not self.vdim:
+                self.op.reverse_overlap, self.op.n_ghost_rows = 1, self.ghost.numel()
+                self.op.ghost_rows = self.ghost.data_ptr() if self.ghost.numel() else None
+        # BilinearForm::Mult is the unconstrained operator: the same tables without the essential list
+        self.op_free = capi.PaOperator.from_buffer_copy(self.op)
+        self.op_free.ness, self.op_free.ess, self.op_free.ess_marker, self.op_free.masked_gather_map = 0, None, None, None
         self._dinv = None
         self._ws = None
         self._comm = None

@@ -34,7 +34,7 @@ class PaOperator(C.Structure):
                 ("masked_gather_map", vp), ("offsets", vp), ("indices", vp),
                 ("ness", i64), ("ess", vp), ("ess_marker", vp), ("yE", vp),
                 ("vdim", cint), ("byvdim", cint), ("pa_comp_stride", i64), ("direct_rows", i64),
-                ("packed_indices", vp), ("e_split", i64)]
+                ("packed_indices", vp), ("e_split", i64), ("reverse_overlap", cint), ("ghost_rows", vp), ("n_ghost_rows", i64)]
 
 
 AR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
@@ -42,8 +42,9 @@ EX_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
 
 
 class Comm(C.Structure):
-    """struct mfem_amd_comm"""
-    _fields_ = [("ctx", vp), ("allreduce_sum", AR_FN), ("forward", EX_FN), ("reverse", EX_FN)]
+    """struct mfem_amd_comm (reverse_begin / reverse_end are optional: NULL when the transport does not split P^T)"""
+    _fields_ = [("ctx", vp), ("allreduce_sum", AR_FN), ("forward", EX_FN), ("reverse", EX_FN),
+                ("reverse_begin", EX_FN), ("reverse_end", EX_FN)]
 
 
 class PcgResult(C.Structure):

@@ -385,8 +385,10 @@ int cb_forward(void *ctx, double *v, void *stream)
    return 0;
 }
 
-// P^T: owners += the ghost entries of the sharing ranks, in fixed neighbour order; ghosts := 0 (:5503-5539)
-int cb_reverse(void *ctx, double *v, void *stream)
+// P^T in two halves (struct mfem_amd_comm: reverse_begin / reverse_end).  begin: pack the ghost entries of v and move
+// them into the owners' receive buffers; v is only read, so the caller may run it on a second stream while the
+// transpose-gather is still summing the rows it does not send.
+int cb_reverse_begin(void *ctx, const double *v, void *stream)
 {
    mfem_amd_exchange *ex = (mfem_amd_exchange*)ctx;
    hipStream_t s = (hipStream_t)stream;
@@ -411,12 +413,26 @@ int cb_reverse(void *ctx, double *v, void *stream)
          if (send_all(w->fds[(size_t)ex->lo_ranks[k]], ex->ext_host + lo[k], sizeof(double)*(size_t)ex->lo_sizes[k])) { return 1; }
       }
       if (nr) { COMM_HIP(hipMemcpyAsync(ex->shr_buf, ex->shr_host, sizeof(double)*(size_t)nr, hipMemcpyHostToDevice, s)); }
+      return 0;
    }
-   else if (int rc = transfer(ex, ex->ext_buf, ex->ext_host, ex->lo_ranks, ex->lo_sizes, ex->shr_buf, ex->shr_host,
-                              ex->up_ranks, ex->up_sizes, s)) { return rc; }
+   return transfer(ex, ex->ext_buf, ex->ext_host, ex->lo_ranks, ex->lo_sizes, ex->shr_buf, ex->shr_host,
+                   ex->up_ranks, ex->up_sizes, s);
+}
+
+// end: owners += what arrived, in fixed neighbour order; ghosts := 0 (fem/pfespace.cpp:5475-5494, :5503-5539)
+int cb_reverse_end(void *ctx, double *v, void *stream)
+{
+   mfem_amd_exchange *ex = (mfem_amd_exchange*)ctx;
    COMM_ABI(mfem_amd_shared_accumulate(ex->nuniq, ex->unq_ltdof, ex->unq_shr_i, ex->unq_shr_j, ex->shr_buf, v, stream));
    COMM_ABI(mfem_amd_set_subvector(ex->next, ex->ext_ldof, nullptr, 0.0, v, stream));
    return 0;
+}
+
+// P^T: owners += the ghost entries of the sharing ranks, in fixed neighbour order; ghosts := 0 (:5503-5539)
+int cb_reverse(void *ctx, double *v, void *stream)
+{
+   if (int rc = cb_reverse_begin(ctx, v, stream)) { return rc; }
+   return cb_reverse_end(ctx, v, stream);
 }
 
 // in-place sum over ranks of n device doubles (InnerProduct: n = 1)
@@ -480,6 +496,8 @@ extern "C" int mfem_amd_exchange_create(mfem_amd_world *world, int nup, const in
    comm->allreduce_sum = cb_allreduce;
    comm->forward = cb_forward;
    comm->reverse = cb_reverse;
+   comm->reverse_begin = cb_reverse_begin;
+   comm->reverse_end = cb_reverse_end;
    *exchange = ex;
    return 0;
 }

@@ -683,6 +683,56 @@ int scatter_dot(int64_t ndofs, const int *offsets, const int *indices, const dou
    return 0;
 }
 
+// The rows of a list summed ahead of the full pass (partitioned runs: the ghost rows, whose sums travel to their owners
+// while k_scatter works on all rows -- which writes the same bits into them again).  Same sequential left-to-right
+// sums from 0, same essential-row patch.  Rows >= nrows (element-interior rows, written by the element kernel; never
+// ghosts) are left alone.  The lists are short (the surface of a rank's part): one row per thread, four entries in flight.
+__global__ void __launch_bounds__(256)
+k_scatter_list(const int64_t nlist, const int *__restrict__ rows, const int64_t nrows, const int *__restrict__ offsets,
+               const int *__restrict__ indices, const double *__restrict__ xE, double *__restrict__ y,
+               const unsigned char *__restrict__ marker, const double *__restrict__ xin, const int *__restrict__ skip)
+{
+   if (skip && *skip) { return; }
+   for (int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x; i < nlist; i += (int64_t)gridDim.x*256)
+   {
+      const int64_t row = rows[i];
+      if (row < 0 || row >= nrows) { continue; }
+      const int o0 = offsets[row], n = offsets[row + 1] - o0;
+      int id[4];
+      double t[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) { id[k] = n > 0 ? indices[o0 + (k < n ? k : n - 1)] : 0; }
+#pragma unroll
+      for (int k = 0; k < 4; k++) { t[k] = n > 0 ? xE[id[k] >= 0 ? id[k] : -1 - id[k]] : 0.0; }
+      double a = 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) { if (k < n) { a += id[k] >= 0 ? t[k] : -t[k]; } }
+      for (int k = 4; k < n; k++)
+      {
+         const int idx = indices[o0 + k];
+         const double tt = xE[idx >= 0 ? idx : -1 - idx];
+         a += idx >= 0 ? tt : -tt;
+      }
+      if (marker)
+      {
+         const unsigned char m = marker[row];
+         if (m) { a = (m == 1) ? xin[row] : 0.0; }
+      }
+      y[row] = a;
+   }
+}
+
+int scatter_list(int64_t nlist, const int *rows, int64_t nrows, const int *offsets, const int *indices, const double *xE,
+                 double *y, const unsigned char *marker, const double *xin, const int *skip, hipStream_t s)
+{
+   if (nlist <= 0) { return 0; }
+   const int64_t nb = (nlist + 255)/256;
+   k_scatter_list<<<dim3((unsigned)(nb < 65536 ? nb : 65536)), dim3(256), 0, s>>>(nlist, rows, nrows, offsets, indices, xE, y,
+                                                                                 marker, xin, skip);
+   MFA_CHECK_LAUNCH("k_scatter_list");
+   return 0;
+}
+
 // vector-space variant of scatter_dot (rows = vdofs)
 int scatter_dot_vec(int64_t ndofs, int nd, int vd, int byvdim, const int *offsets, const int *indices,
                     const double *xE, double *y, const unsigned char *marker, const double *xin,

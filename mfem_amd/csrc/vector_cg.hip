@@ -28,6 +28,8 @@ int scatter_dot_vec(int64_t ndofs, int nd, int vd, int byvdim, const int *offset
                     const double *w, double *partials, int nblocks, const int *skip, hipStream_t s);
 int pa_apply_L2E(int kind, int layout, int D, int Q, int64_t ne, const double *B, const double *G,
                  const double *Dq, const int *gmap, const double *x, double *yE, hipStream_t s, double *ydir);
+int scatter_list(int64_t nlist, const int *rows, int64_t nrows, const int *offsets, const int *indices, const double *xE,
+                 double *y, const unsigned char *marker, const double *xin, const int *skip, hipStream_t s);
 int scatter_dot(int64_t ndofs, const int *offsets, const int *indices, const double *xE,
                 double *y, const unsigned char *marker, const double *xin, const double *w,
                 double *partials, int nblocks, const int *skip, hipStream_t s, int64_t ndirect);
@@ -445,21 +447,25 @@ static int apply_range(const mfem_amd_pa_operator *op, const int *gm, const doub
                        op->yE + e0*(nd ? D3 - NI : D3), s, nd ? y + nrows + e0*NI : nullptr);
 }
 
-// a second stream and two events per device for the exchange that runs beside the interior elements (created on first use)
-static int overlap_objects(hipStream_t *side, hipEvent_t *ev_x, hipEvent_t *ev_ghosts)
+// a second stream and four events per device for the exchanges that run beside the kernels (created on first use)
+struct OverlapObjects { hipStream_t side; hipEvent_t x_ready, ghosts_in, ghost_rows_summed, sent; };
+static int overlap_objects(OverlapObjects *oo)
 {
-   static hipStream_t st[64] = {nullptr};
-   static hipEvent_t ea[64] = {nullptr}, eb[64] = {nullptr};
+   static OverlapObjects obj[64] = {};
    int dev = 0;
    if (int rc = check_hip(hipGetDevice(&dev), "hipGetDevice")) { return rc; }
    if (dev < 0 || dev >= 64) { set_error("pa operator: device index %d out of range", dev); return 1; }
-   if (!st[dev])
+   if (!obj[dev].side)
    {
-      if (int rc = check_hip(hipStreamCreateWithFlags(&st[dev], hipStreamNonBlocking), "hipStreamCreateWithFlags")) { return rc; }
-      if (int rc = check_hip(hipEventCreateWithFlags(&ea[dev], hipEventDisableTiming), "hipEventCreateWithFlags")) { return rc; }
-      if (int rc = check_hip(hipEventCreateWithFlags(&eb[dev], hipEventDisableTiming), "hipEventCreateWithFlags")) { return rc; }
+      OverlapObjects o = {};
+      if (int rc = check_hip(hipStreamCreateWithFlags(&o.side, hipStreamNonBlocking), "hipStreamCreateWithFlags")) { return rc; }
+      for (hipEvent_t *e : {&o.x_ready, &o.ghosts_in, &o.ghost_rows_summed, &o.sent})
+      {
+         if (int rc = check_hip(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreateWithFlags")) { return rc; }
+      }
+      obj[dev] = o;
    }
-   *side = st[dev]; *ev_x = ea[dev]; *ev_ghosts = eb[dev];
+   *oo = obj[dev];
    return 0;
 }
 
@@ -522,22 +528,43 @@ static int constrained_mult(const mfem_amd_pa_operator *op, const mfem_amd_comm 
    MFA_REQUIRE(nd >= 0 && nd <= op->ndofs, "pa operator: direct_rows out of range");
    const int64_t nrows = op->ndofs - nd;
    if (nd && !w) { nb = (int)((nrows + 1023)/1024 > 0 ? (nrows + 1023)/1024 : 1); }
+   // The other direction: with the rank's ghost rows listed (op->reverse_overlap) and a transport that offers the two
+   // halves of P^T, those rows are summed first and travel to their owners on the second stream while the
+   // transpose-gather sums all rows (it writes the same bits into the ghost rows again); the owners add what arrived
+   // once both are done.  The full pass is launched BEFORE the transport is called, as above.
+   static const bool reverse_ok = !(getenv("MFEM_AMD_OVERLAP_REVERSE") && atoi(getenv("MFEM_AMD_OVERLAP_REVERSE")) == 0);
+   const bool rsplit = comm && overlap_ok && reverse_ok && op->reverse_overlap && comm->reverse_begin && comm->reverse_end;
+   MFA_REQUIRE(!rsplit || (op->n_ghost_rows >= 0 && (op->ghost_rows || op->n_ghost_rows == 0)), "pa operator: reverse_overlap without ghost_rows");
+   OverlapObjects oo = {};
+   if (overlap || rsplit) { if (int rc = overlap_objects(&oo)) { return rc; } }
    if (overlap)
    {
-      hipStream_t side; hipEvent_t ev_x, ev_ghosts;
-      if (int rc = overlap_objects(&side, &ev_x, &ev_ghosts)) { return rc; }
-      if (int rc = check_hip(hipEventRecord(ev_x, s), "hipEventRecord")) { return rc; }
-      if (int rc = check_hip(hipStreamWaitEvent(side, ev_x, 0), "hipStreamWaitEvent")) { return rc; }
+      if (int rc = check_hip(hipEventRecord(oo.x_ready, s), "hipEventRecord")) { return rc; }
+      if (int rc = check_hip(hipStreamWaitEvent(oo.side, oo.x_ready, 0), "hipStreamWaitEvent")) { return rc; }
       if (int rc = apply_range(op, gm, x, y, nd, nrows, 0, op->e_split, s)) { return rc; }
-      if (int rc = comm->forward(comm->ctx, x, (void*)side)) { set_error("comm forward exchange failed (%d)", rc); return rc; }
-      if (int rc = check_hip(hipEventRecord(ev_ghosts, side), "hipEventRecord")) { return rc; }
-      if (int rc = check_hip(hipStreamWaitEvent(s, ev_ghosts, 0), "hipStreamWaitEvent")) { return rc; }
+      if (int rc = comm->forward(comm->ctx, x, (void*)oo.side)) { set_error("comm forward exchange failed (%d)", rc); return rc; }
+      if (int rc = check_hip(hipEventRecord(oo.ghosts_in, oo.side), "hipEventRecord")) { return rc; }
+      if (int rc = check_hip(hipStreamWaitEvent(s, oo.ghosts_in, 0), "hipStreamWaitEvent")) { return rc; }
       if (int rc = apply_range(op, gm, x, y, nd, nrows, op->e_split, op->ne, s)) { return rc; }
    }
    else if (int rc = apply_range(op, gm, x, y, nd, nrows, 0, op->ne, s)) { return rc; }
-   if (int rc = scatter_dot(nrows, op->offsets, nd ? op->packed_indices : op->indices, op->yE, y, ess ? op->ess_marker : nullptr,
-                            x, w, partials, nb, skip, s, nd)) { return rc; }
-   if (comm)
+   const int *ind = nd ? op->packed_indices : op->indices;
+   const unsigned char *mk = ess ? op->ess_marker : nullptr;
+   if (rsplit)
+   {
+      if (int rc = scatter_list(op->n_ghost_rows, op->ghost_rows, nrows, op->offsets, ind, op->yE, y, mk, x, skip, s)) { return rc; }
+      if (int rc = check_hip(hipEventRecord(oo.ghost_rows_summed, s), "hipEventRecord")) { return rc; }
+   }
+   if (int rc = scatter_dot(nrows, op->offsets, ind, op->yE, y, mk, x, w, partials, nb, skip, s, nd)) { return rc; }
+   if (rsplit)
+   {
+      if (int rc = check_hip(hipStreamWaitEvent(oo.side, oo.ghost_rows_summed, 0), "hipStreamWaitEvent")) { return rc; }
+      if (int rc = comm->reverse_begin(comm->ctx, y, (void*)oo.side)) { set_error("comm reverse exchange (begin) failed (%d)", rc); return rc; }
+      if (int rc = check_hip(hipEventRecord(oo.sent, oo.side), "hipEventRecord")) { return rc; }
+      if (int rc = check_hip(hipStreamWaitEvent(s, oo.sent, 0), "hipStreamWaitEvent")) { return rc; }
+      if (int rc = comm->reverse_end(comm->ctx, y, (void*)s)) { set_error("comm reverse exchange (end) failed (%d)", rc); return rc; }
+   }
+   else if (comm)
    {
       if (int rc = comm->reverse(comm->ctx, y, (void*)s)) { set_error("comm reverse exchange failed (%d)", rc); return rc; }
    }

@@ -299,7 +299,20 @@ ParPAOperator::ParPAOperator(const PABilinearFormExtension &ext, const ParFinite
    cop.ness = ness; cop.ess = ness ? ess.Read() : nullptr; cop.ess_marker = marker.Read();
    SetSplit();
 }
-void ParPAOperator::SetSplit() const { cop.e_split = interior_split(cop, pfes->GetParMesh()->InteriorElements()); }
+// ... and the ghost -> owner exchange beside the transpose-gather (mfem_amd_pa_operator::reverse_overlap): the rank's ghost dofs
+static void ghost_rows(mfem_amd_pa_operator &op, const ParFiniteElementSpace &pf)
+{
+   if (op.vdim > 0 || op.kind == 2) { return; }
+   const Array<int> &gh = pf.GhostDofs();
+   op.reverse_overlap = 1;
+   op.n_ghost_rows = gh.Size();
+   op.ghost_rows = gh.Size() ? gh.Read() : nullptr;
+}
+void ParPAOperator::SetSplit() const
+{
+   cop.e_split = interior_split(cop, pfes->GetParMesh()->InteriorElements());
+   ghost_rows(cop, *pfes);
+}
 // as ConstrainedOperator::RefreshOperator (fem.cpp): the form's buffers may have moved since construction
 void ParPAOperator::RefreshOperator() const
 {
@@ -326,6 +339,7 @@ void ParBilinearForm::Mult(const Vector &x, Vector &y) const
    {
       // the unconstrained P^T A P in one library call: the owner -> ghost exchange beside the interior elements
       op.e_split = interior_split(op, pfes->GetParMesh()->InteriorElements());
+      ghost_rows(op, *pfes);
       y.SetSize(xx.Size());
       MFEM_AMD_CALL(mfem_amd_pa_par_mult(&op, pfes->Comm(), xx.ReadWrite(), y.Write(), nullptr));
       return;

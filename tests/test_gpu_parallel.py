@@ -336,6 +336,18 @@ def _native_worker(rank, world, port, problem, p, n, out, mode, transport):
         assert float(yl[bp.ghost.long()].abs().max()) == 0.0 if bp.ghost.numel() else True
         if vd == 1:
             _oracle_checks(problem, p, sp, bp, l2g, own, xg, yl, X, b)       # the transport that ships, against the oracle
+            # the ghost -> owner exchange beside the transpose-gather (op.reverse_overlap: ghost rows summed first, the two
+            # halves of P^T on two streams) ran in everything above; with it switched off -- the exchange after the
+            # transpose-gather, one stream -- the same bits come out of the apply and of the solver
+            assert bp.op.reverse_overlap == 1 and bp.op.n_ghost_rows == bp.ghost.numel()
+            assert bool(ex.comm.reverse_begin) and bool(ex.comm.reverse_end)
+            bp.op.reverse_overlap = bp.op_free.reverse_overlap = 0
+            yl2 = torch.empty_like(xl); bp.mult(xl, yl2)
+            X2, res2, hist2 = bp.pcg(b, 1e-10, max_iter=1000, check_every=4, want_hist=True)
+            torch.cuda.synchronize()
+            assert torch.equal(yl, yl2) and torch.equal(X, X2) and res2.iterations == res.iterations
+            assert np.array_equal(hist, hist2)
+            bp.op.reverse_overlap = bp.op_free.reverse_overlap = 1
         w.barrier()
         ex.close(); w.close()
         out.put((rank, "ok"))
