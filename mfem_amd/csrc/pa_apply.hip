@@ -47,6 +47,22 @@ constexpr int minw_for(int KIND, int D, int PF = 0, int RB = 1, bool VEC = false
    return KIND ? (D <= 5 ? 3 : D <= 7 ? 2 : 1) : (D <= 7 ? 3 : 2);
 }
 
+// Staged stores (kernel comment at the copy-out): which specialisations send their packed E-vector entries and interior rows
+// through LDS and out as whole lines.  Measured A/B on one box, whole apply at 1e7 dofs on the reference's numbering
+// (profiles/r3/staged_stores_ab.txt): BP1 p = 2..7 +1.3..4.0 %, p = 8 -1.4 %; BP3 p = 2 +0.8, p = 3 -1.5, p = 4 +2.5, p = 5, 6
+// +0.3 / 0, p = 7 -1.0, p = 8 +0.9 %; BP5 p = 2, 3 -0.6 / -3.5, p = 4..7 +0.8 / 3.3 / 3.8 / 0.5, p = 8 -4.7 %.
+// MFA_STAGE_STORE=0 | 1 (build) forces it off / on everywhere.
+#ifndef MFA_STAGE_STORE
+#define MFA_STAGE_STORE -1
+#endif
+constexpr bool stage_store_for(int KIND, int D, int Q)
+{
+   if (MFA_STAGE_STORE >= 0) { return MFA_STAGE_STORE != 0; }
+   if (KIND == 0) { return D <= 8; }
+   if (Q == D) { return D >= 5 && D <= 8; }
+   return D != 4 && D != 8;
+}
+
 // KIND: 0 mass, 1 diffusion.  GATHER: x is an L-vector read through gmap (entries < 0 read
 // as 0.0), else x is an E-vector.  ACCUM: yE += (AddMultPA semantics) else yE =.
 //
@@ -91,6 +107,9 @@ constexpr int minw_for(int KIND, int D, int PF = 0, int RB = 1, bool VEC = false
 #endif
 #ifndef MFA_SPLIT_O
 #define MFA_SPLIT_O 1
+#endif
+#ifndef MFA_STAGE_W16
+#define MFA_STAGE_W16 -1
 #endif
 // tuning builds: -DMFA_ONLY_D=<D1D> compiles the specialisations of one D1D only (seconds instead of minutes)
 #ifndef MFA_ONLY_D
@@ -158,6 +177,9 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
    constexpr int NF = KIND ? 3 : 1;       // fields carried through the z loop
    constexpr int NX = KIND ? 2 : 1;       // fields after the x contraction (B x, G x)
    constexpr bool DIRECT = GATHER && !ACCUM && !VEC && ABL == 0 && D >= 3;   // va.ydirect honoured
+   constexpr bool STG = DIRECT && stage_store_for(KIND, D, Q);               // ... through LDS, as whole lines
+   // (16 bytes a lane in the copy-out, except where that form costs the kernel a spilled x value: MFA_STAGE_W16 = 0 | 1 forces)
+   constexpr bool STG16 = MFA_STAGE_W16 < 0 ? !(KIND == 1 && D == 5 && Q == 6 && RB == 1) : (MFA_STAGE_W16 != 0);
    // LDS strides (doubles): rows that one thread walks (sX, sBX/sGX, sV) are padded to an odd
    // length; the (qy,qx) planes of sT keep dense rows and get a small pad as a whole for even Q.
    // (Measured: padding or transposing the planes so that the row-per-thread reads are entirely
@@ -775,7 +797,17 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
                // what is left of the element goes to the packed E-vector (common.h: packed_pos): this row's two end
                // entries and its run of D-2 middle entries -- an x-edge, a row of a z- or y-face, or (inner rows)
                // the interior run
-               if (DIRECT && va.ydirect)
+               if (STG && va.ydirect)
+               {
+                  // staged stores (below): the row's values go to their packed positions in the element's dead region A --
+                  // [0, NS) the surviving entries, [NS, D^3) the interior run -- and leave the workgroup as two contiguous runs
+                  constexpr int NSP = packed_size(D);
+                  const int code = sTab[t2];
+                  const int p0 = code & 1023, dl = (code >> 10) & 1023, pm = ((code >> 20) & 1023) + (((code >> 30) & 1) ? NSP : 0);
+#pragma unroll
+                  for (int dx = 0; dx < D; dx++) { sA[dx == 0 ? p0 : (dx == D - 1 ? p0 + dl : pm + dx - 1)] = yv[dx]; }
+               }
+               else if (DIRECT && va.ydirect)
                {
                   // One store per value, its address chosen per lane by mask arithmetic: the rows of one wave differ in
                   // kind, and a branch would issue both forms of the row one after the other.  (Not `c ? p : q` on the
@@ -798,6 +830,9 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
 #pragma unroll
                   for (int dx = 0; dx < D; dx++)
                   {
+#ifdef MFA_PROBE_NOSTORE   // probe builds only (tools/r3_job13.sh): what the store phase costs -- the values stay live, nothing is written
+                     if (yv[dx] != 1.2345e-300) { continue; }
+#endif
                      *reinterpret_cast<gdouble*>(dx == 0 ? a0 : (dx == D - 1 ? a0 + 8u*(unsigned)dl : am + 8u*(dx - 1))) = yv[dx];
                   }
                }
@@ -840,7 +875,13 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
                   y += Bc[qx]*sV[(dz*D + b)*QP + qx];
                   if (KIND) { y += Gc[qx]*sV[DDQ + (dz*D + b)*QP + qx]; }
                }
-               if (DIRECT && va.ydirect)
+               if (STG && va.ydirect)
+               {
+                  constexpr int DI = D - 2, NSP = packed_size(D);
+                  const int pp = packed_pos(D, dz, b, a);
+                  sA[pp < 0 ? NSP + ((dz - 1)*DI + (b - 1))*DI + (a - 1) : pp] = y;      // staged stores (below)
+               }
+               else if (DIRECT && va.ydirect)
                {
                   constexpr int DI = D - 2;
                   const bool inner = a >= 1 && a <= DI && b >= 1 && b <= DI && dz >= 1 && dz <= DI;
@@ -852,6 +893,58 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
                else if (ACCUM) { ye[dz*D*D] += y; }
                else { ye[dz*D*D] = y; }
             }
+         }
+         if (STG && va.ydirect)
+         {
+            // Staged stores: a row thread's D values land at scattered packed positions, 8 bytes a lane -- tens of partial
+            // write requests per wave instruction, and the memory pipeline of a CU moves requests, not bytes
+            // (profiles/r3/store_probe.txt).  From LDS the workgroup's elements leave as two contiguous runs instead: the
+            // batch's packed E-vector entries (NBZ*NS doubles) and its interior rows of y (NBZ*(D-2)^3), whole lines per
+            // wave instruction.  Same values at the same addresses.
+            constexpr int NSP = packed_size(D), NIP = D3 - NSP, STRIDE = SA + SV, NT = QQ*NBZ;
+            __syncthreads();
+            // (an opaque copy of the thread's index: everything the copy-out derives from it is formed here, after the z loop,
+            // instead of being hoisted above it, where the (5,6) kernel has no register to spare)
+            int tid;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(tid) : "v"(t2 + QQ*tz));
+            const int64_t e0 = bt*NBZ;
+            const int nact = (int)(ne - e0 < NBZ ? ne - e0 : NBZ);
+            const double *sm = &smem[0][0];
+            // 16 bytes a lane (8-byte accesses run at 0.5-0.7 of that rate, MI355X_MICROARCH.md): pairs (i, i+1) from the first
+            // 16-byte-aligned double of the run on; its possible leading double and the run's last one go alone
+            auto copy_out = [&](double *dst, const int n, auto per_c, auto off_c)
+            {
+               constexpr int per = decltype(per_c)::value, off = decltype(off_c)::value;
+               auto at = [&](const int i) { const int ee = i/per; return sm[ee*STRIDE + off + (i - ee*per)]; };
+               if (!STG16)
+               {
+#pragma unroll
+                  for (int k = 0; k < (NBZ*per + NT - 1)/NT; k++)
+                  {
+                     const int i = tid + k*NT;
+                     if (i < n) { dst[i] = at(i); }
+                  }
+                  return;
+               }
+               const int mis = (int)((reinterpret_cast<uint64_t>(dst) >> 3) & 1);
+               const int npairs = (n - mis)/2;
+#pragma unroll
+               for (int k = 0; k < (NBZ*per/2 + NT - 1)/NT; k++)
+               {
+                  const int j = tid + k*NT;
+                  if (j < npairs)
+                  {
+                     const int i = mis + 2*j;
+                     double2 v; v.x = at(i); v.y = at(i + 1);
+                     *reinterpret_cast<double2*>(dst + i) = v;
+                  }
+               }
+               if (tid == 0 && mis && n > 0) { dst[0] = at(0); }
+               if (tid == 1 && ((n - mis) & 1) && n > mis) { dst[n - 1] = at(n - 1); }
+            };
+            copy_out(yE + e0*NSP, nact*NSP, std::integral_constant<int, NSP>{}, std::integral_constant<int, 0>{});
+            copy_out(va.ydirect + e0*NIP, nact*NIP, std::integral_constant<int, NIP>{}, std::integral_constant<int, NSP>{});
+            if (PERSIST) { __syncthreads(); }      // the next batch's x values are staged in region A
          }
          // no barrier needed here: the next iteration writes sX (region A), whose last readers
          // (the transposed y contraction) are behind the barrier above; sV is next written
