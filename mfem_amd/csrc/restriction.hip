@@ -160,7 +160,13 @@ __device__ __forceinline__ void scatter_block_rows(const int64_t ndofs, const in
       {
          if (256*k < cnt)
          {
+#if defined(MFA_E2L_PROBE) && MFA_E2L_PROBE == 1          // probe builds only (tools/r3_job17.sh): no gather at all
+            v[k] = (double)id[k];
+#elif defined(MFA_E2L_PROBE) && MFA_E2L_PROBE == 2        // ... a gather that always hits (a 32 KB window of the E-vector)
+            v[k] = xE[(id[k] >= 0 ? id[k] : -1 - id[k]) & 4095];
+#else
             v[k] = xE[id[k] >= 0 ? id[k] : -1 - id[k]];       // re-used across the four sweeps of the numbering: cached
+#endif
          }
       }
 #pragma unroll
