@@ -1295,9 +1295,15 @@ static int launch_apply(int64_t ne, const double *B, const double *G, const doub
    if (mode == 0)
    {
       MFA_REQUIRE(nb < (int64_t)2147483647, "pa_apply: too many workgroups (%lld)", (long long)nb);
-      // tuning aid: MFEM_AMD_APPLY_XCD=1 XCD-contiguous batches, >= 4 runs of that many batches per XCD (profiles/r3/xcd_runs.txt)
-      static const int xcd_env = getenv("MFEM_AMD_APPLY_XCD") ? atoi(getenv("MFEM_AMD_APPLY_XCD")) : 0;
-      static const int xcd = xcd_env >= 4 ? xcd_env : xcd_env ? 2 : 1;
+      // Runs of 64 consecutive batches per XCD once the L-vector no longer fits the Infinity Cache (8 B x ~NE (D-1)^3 dofs beyond
+      // 192 MiB): neighbouring batches then share their gathered x lines through one L2 instead of each XCD fetching them from
+      // HBM -- whole apply at p = 4 +0.6 / +1.9 / +3.9 % at 3e7 / 5e7 / 1e8 dofs, PCG +2.8 / +4.1 / +4.3 % (p = 2, 6 at 1e8: +2.2 / +0.7 %;
+      // profiles/r3/xcd_runs_large.txt).  Below that the re-fetched lines are cache hits that cost nothing and the round-robin
+      // order is as fast or faster (xcd_runs.txt, xcd_traffic_probe.txt).  MFEM_AMD_APPLY_XCD forces: 0 round-robin, 1
+      // XCD-contiguous batches, >= 4 runs of that many batches per XCD.
+      static const int xcd_env = getenv("MFEM_AMD_APPLY_XCD") ? atoi(getenv("MFEM_AMD_APPLY_XCD")) : -1;
+      const bool big_x = (int64_t)sizeof(double)*ne*(D - 1)*(D - 1)*(D - 1) > ((int64_t)192 << 20);
+      const int xcd = xcd_env >= 4 ? xcd_env : xcd_env > 0 ? 2 : xcd_env == 0 ? 1 : (big_x ? 64 : 1);
       kern1<<<dim3((unsigned)nb), dim3(Q, Q, NBZ), 0, s>>>(ne, nb, xcd, bg, Dq, x, gmap, yE, va);
    }
    else
