@@ -33,10 +33,16 @@ int main(int argc, char *argv[])
    const int me = Mpi::WorldRank(), nranks = Mpi::WorldSize();
    const bool GLL = bp >= 5, mass = bp <= 2;
    const int VDIM = (bp % 2 == 0) ? 3 : 1;
+   // set-up times of this rank: the serial mesh (every rank builds it, as the reference's ex1p reads it), the rank's part,
+   // the space with its shared-dof tables (work of the rank's part and its surface, not of the global problem)
+   double ts = now();
    Mesh mesh = Mesh::MakeCartesian3D(N, N, N, Element::HEXAHEDRON, 1.0, 1.0, 1.0, true);
+   const double t_mesh = now() - ts; ts = now();
    ParMesh pmesh(MPI_COMM_WORLD, mesh);
+   const double t_pmesh = now() - ts; ts = now();
    H1_FECollection fec(p, 3, BasisType::GaussLobatto);
    ParFiniteElementSpace fes(&pmesh, &fec, VDIM, VDIM == 3 ? Ordering::byVDIM : Ordering::byNODES);
+   const double t_space = now() - ts;
    IntegrationRules irs(0, GLL ? Quadrature1D::GaussLobatto : Quadrature1D::GaussLegendre);
    const IntegrationRule *ir = &irs.Get(Geometry::CUBE, 2*p + (GLL ? -1 : 3));
    ConstantCoefficient one(1.0);
@@ -92,9 +98,10 @@ int main(int argc, char *argv[])
    if (me == 0)
    {
       printf("{\"phase\": \"problem\", \"ranks\": %d, \"bp\": %d, \"p\": %d, \"N\": %d, \"dofs\": %lld, \"iterations\": %d, \"converged\": %d, "
-             "\"norm_X\": %.15e, \"norm_AX\": %.15e, \"solve_s\": %.6f, \"ms_per_apply\": %.6f}\n", nranks, bp, p, N,
+             "\"norm_X\": %.15e, \"norm_AX\": %.15e, \"solve_s\": %.6f, \"ms_per_apply\": %.6f, "
+             "\"serial_mesh_s\": %.3f, \"par_mesh_s\": %.3f, \"par_space_s\": %.3f, \"local_dofs\": %d}\n", nranks, bp, p, N,
              (long long)fes.GlobalTrueVSize(), cg.GetNumIterations(), (int)cg.GetConverged(), std::sqrt(s[0]), std::sqrt(s[1]),
-             t_solve, t_apply*1e3);
+             t_solve, t_apply*1e3, t_mesh, t_pmesh, t_space, fes.GetVSize());
       fflush(stdout);
    }
    return 0;

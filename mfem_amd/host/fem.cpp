@@ -116,42 +116,72 @@ void FiniteElementSpace::Update()
    delete R_lex; R_lex = nullptr;
    Construct();
 }
-// fem/fespace.cpp:3392-3500 on a conforming hexahedral mesh
+// fem/fespace.cpp:3392-3500 on a conforming hexahedral mesh: vertex, edge (oriented), face (oriented), interior dofs
+int64_t FiniteElementSpace::NDofsOf(const Mesh &m, int p)
+{
+   const int64_t ne1 = p - 1, nf1 = ne1*ne1, nb1 = nf1*ne1;
+   return (int64_t)m.GetNV() + (int64_t)m.GetNEdges()*ne1 + (int64_t)m.GetNFaces()*nf1 + (int64_t)m.GetNE()*nb1;
+}
+void FiniteElementSpace::ElementDofsOf(const Mesh &m, const H1_FECollection &h1, int e, int64_t *dofs)
+{
+   const int p = h1.GetOrder(), ne1 = p - 1, nf1 = ne1*ne1, nb1 = nf1*ne1;
+   const int64_t nv = m.GetNV(), ned = (int64_t)m.GetNEdges()*ne1, nfd = (int64_t)m.GetNFaces()*nf1;
+   static const int hex_edges[12][2] = { {0,1},{1,2},{3,2},{0,3},{4,5},{5,6},{7,6},{4,7},{0,4},{1,5},{2,6},{3,7} };
+   const int *v = m.GetElementVertices(e);
+   int o = 0;
+   for (int i = 0; i < 8; i++) { dofs[o++] = v[i]; }
+   if (!ne1) { return; }
+   const int *E = m.GetElementEdges(e);
+   for (int i = 0; i < 12; i++)
+   {
+      const int ori = (v[hex_edges[i][0]] < v[hex_edges[i][1]]) ? 1 : -1;     // mesh.cpp:7835-7855
+      const int *ind = h1.SegDofOrder(ori);
+      for (int j = 0; j < ne1; j++) { dofs[o++] = nv + (int64_t)E[i]*ne1 + ind[j]; }
+   }
+   const int *F = m.GetElementFaces(e);
+   for (int i = 0; i < 6; i++)
+   {
+      const int *ind = h1.QuadDofOrder(m.GetElementFaceOrientation(e, i));
+      for (int j = 0; j < nf1; j++) { dofs[o++] = nv + ned + (int64_t)F[i]*nf1 + ind[j]; }
+   }
+   const int64_t bbase = nv + ned + nfd + (int64_t)e*nb1;
+   for (int j = 0; j < nb1; j++) { dofs[o++] = bbase + j; }
+}
+// fem/fespace.cpp:3509-: vertices, edges (oriented), the face (oriented w.r.t. its base)
+void FiniteElementSpace::BdrElementDofsOf(const Mesh &m, const H1_FECollection &h1, int b, int64_t *dofs)
+{
+   const int p = h1.GetOrder(), ne1 = p - 1, nf1 = ne1*ne1;
+   const int64_t nv = m.GetNV(), ned = (int64_t)m.GetNEdges()*ne1;
+   static const int quad_edges[4][2] = { {0,1},{1,2},{2,3},{3,0} };
+   const int *v = m.GetBdrElementVertices(b);
+   int o = 0;
+   for (int i = 0; i < 4; i++) { dofs[o++] = v[i]; }
+   if (!ne1) { return; }
+   const int *E = m.GetBdrElementEdges(b);
+   for (int i = 0; i < 4; i++)
+   {
+      const int *ind = h1.SegDofOrder((v[quad_edges[i][0]] < v[quad_edges[i][1]]) ? 1 : -1);
+      for (int j = 0; j < ne1; j++) { dofs[o++] = nv + (int64_t)E[i]*ne1 + ind[j]; }
+   }
+   const int f = m.GetBdrElementFaceIndex(b);
+   const int *ind = h1.QuadDofOrder(Mesh::GetQuadOrientation(m.GetFaceVertices(f), v));
+   for (int j = 0; j < nf1; j++) { dofs[o++] = nv + ned + (int64_t)f*nf1 + ind[j]; }
+}
 void FiniteElementSpace::Construct()
 {
    const int p = fec->GetOrder(), ne1 = p - 1, nf1 = ne1*ne1, nb1 = nf1*ne1;
    const int NE = mesh->GetNE(), nd = (p + 1)*(p + 1)*(p + 1);
-   const int64_t total = (int64_t)mesh->GetNV() + (int64_t)mesh->GetNEdges()*ne1 + (int64_t)mesh->GetNFaces()*nf1 + (int64_t)NE*nb1;
+   const int64_t total = NDofsOf(*mesh, p);
    MFEM_VERIFY(total*vdim < 2147483647LL && (int64_t)NE*nd < 2147483647LL,
                "mfem_amd: the space exceeds 32-bit dof indices; partition it over more ranks");
    nvdofs = mesh->GetNV(); nedofs = mesh->GetNEdges()*ne1; nfdofs = mesh->GetNFaces()*nf1; nbdofs = NE*nb1;
    ndofs = nvdofs + nedofs + nfdofs + nbdofs;
    elem_dof.resize((size_t)NE*nd);
-   static const int hex_edges[12][2] = { {0,1},{1,2},{3,2},{0,3},{4,5},{5,6},{7,6},{4,7},{0,4},{1,5},{2,6},{3,7} };
+   std::vector<int64_t> d((size_t)nd);
    for (int e = 0; e < NE; e++)
    {
-      int *dofs = &elem_dof[(size_t)e*nd];
-      const int *v = mesh->GetElementVertices(e);
-      int o = 0;
-      for (int i = 0; i < 8; i++) { dofs[o++] = v[i]; }
-      if (ne1)
-      {
-         const int *E = mesh->GetElementEdges(e);
-         for (int i = 0; i < 12; i++)
-         {
-            const int ori = (v[hex_edges[i][0]] < v[hex_edges[i][1]]) ? 1 : -1;     // mesh.cpp:7835-7855
-            const int *ind = h1->SegDofOrder(ori);
-            for (int j = 0; j < ne1; j++) { dofs[o++] = nvdofs + E[i]*ne1 + ind[j]; }
-         }
-         const int *F = mesh->GetElementFaces(e);
-         for (int i = 0; i < 6; i++)
-         {
-            const int *ind = h1->QuadDofOrder(mesh->GetElementFaceOrientation(e, i));
-            for (int j = 0; j < nf1; j++) { dofs[o++] = nvdofs + nedofs + F[i]*nf1 + ind[j]; }
-         }
-         const int bbase = nvdofs + nedofs + nfdofs + e*nb1;
-         for (int j = 0; j < nb1; j++) { dofs[o++] = bbase + j; }
-      }
+      ElementDofsOf(*mesh, *h1, e, d.data());
+      for (int j = 0; j < nd; j++) { elem_dof[(size_t)e*nd + j] = (int)d[(size_t)j]; }
    }
    sequence++;
 }
@@ -161,27 +191,13 @@ void FiniteElementSpace::GetElementDofs(int e, Array<int> &dofs) const
    dofs.SetSize(nd);
    std::copy(ElementDofs(e), ElementDofs(e) + nd, dofs.HostWrite());
 }
-// fem/fespace.cpp:3509-: vertices, edges (oriented), the face (oriented w.r.t. its base)
 void FiniteElementSpace::GetBdrElementDofs(int b, Array<int> &dofs) const
 {
-   const int p = fec->GetOrder(), ne1 = p - 1, nf1 = ne1*ne1;
-   static const int quad_edges[4][2] = { {0,1},{1,2},{2,3},{3,0} };
-   const int *v = mesh->GetBdrElementVertices(b);
-   dofs.SetSize(4 + 4*ne1 + nf1);
-   int o = 0;
-   for (int i = 0; i < 4; i++) { dofs[o++] = v[i]; }
-   if (ne1)
-   {
-      const int *E = mesh->GetBdrElementEdges(b);
-      for (int i = 0; i < 4; i++)
-      {
-         const int *ind = h1->SegDofOrder((v[quad_edges[i][0]] < v[quad_edges[i][1]]) ? 1 : -1);
-         for (int j = 0; j < ne1; j++) { dofs[o++] = nvdofs + E[i]*ne1 + ind[j]; }
-      }
-      const int f = mesh->GetBdrElementFaceIndex(b);
-      const int *ind = h1->QuadDofOrder(Mesh::GetQuadOrientation(mesh->GetFaceVertices(f), v));
-      for (int j = 0; j < nf1; j++) { dofs[o++] = nvdofs + nedofs + f*nf1 + ind[j]; }
-   }
+   const int ne1 = fec->GetOrder() - 1, n = 4 + 4*ne1 + ne1*ne1;
+   std::vector<int64_t> d((size_t)n);
+   BdrElementDofsOf(*mesh, *h1, b, d.data());
+   dofs.SetSize(n);
+   for (int i = 0; i < n; i++) { dofs[i] = (int)d[(size_t)i]; }
 }
 // fem/fespace.cpp:554-670
 void FiniteElementSpace::GetEssentialVDofs(const Array<int> &bdr_attr_is_ess, Array<int> &ess_vdofs, int component) const

@@ -833,6 +833,7 @@ public:
    const int *GetElementEdges(int e) const { return &el_to_edge[12*e]; }
    const int *GetElementFaces(int e) const { return &el_to_face[6*e]; }
    int GetBdrElementFaceIndex(int b) const { return be_to_face[b]; }
+   int GetFaceElement1(int f) const { return face_elem1[f]; }     // the element a face was first seen from (-1: none)
    const int *GetBdrElementEdges(int b) const { return &bel_to_edge[4*b]; }
    const int *GetEdgeVertices(int i) const { return &edge_vertices[2*i]; }
    const int *GetFaceVertices(int f) const { return &face_vertices[4*f]; }
@@ -924,6 +925,12 @@ public:
    void GetElementDofs(int e, Array<int> &dofs) const;
    const int *ElementDofs(int e) const { return &elem_dof[(size_t)e*GetTypicalFE()->GetDof()]; }
    void GetBdrElementDofs(int b, Array<int> &dofs) const;
+   /// The numbering itself, for one (boundary) element of any mesh: the (p+1)^3 (or (p+1)^2) dofs in the native order,
+   /// 64-bit -- what a space on `m` would hold in its table, without building the space (the parallel space numbers the
+   /// elements it needs of the serial mesh this way).  Class offsets follow from the mesh's own entity counts.
+   static void ElementDofsOf(const Mesh &m, const H1_FECollection &h1, int e, int64_t *dofs);
+   static void BdrElementDofsOf(const Mesh &m, const H1_FECollection &h1, int b, int64_t *dofs);
+   static int64_t NDofsOf(const Mesh &m, int order);
    void GetEssentialVDofs(const Array<int> &bdr_attr_is_ess, Array<int> &ess_vdofs, int component = -1) const;
    void GetEssentialTrueDofs(const Array<int> &bdr_attr_is_ess, Array<int> &ess_tdof_list, int component = -1) const;
    void GetBoundaryTrueDofs(Array<int> &boundary_dofs, int component = -1) const;
@@ -1224,8 +1231,11 @@ public:
 class ParFiniteElementSpace : public FiniteElementSpace
 {
    ParMesh *pmesh;
-   FiniteElementSpace *gfes = nullptr;          // the serial space: global dof numbering (every rank has it)
-   Array<int> l2g;                              // local dof -> global dof
+   int64_t global_ndofs = 0;                    // dofs of the serial space (never built: its numbering is evaluated
+                                                // element by element for the rank's elements and their neighbours)
+   std::vector<int64_t> l2g64;                  // local dof -> global dof
+   std::vector<std::pair<int64_t, int>> g2l;    // (global dof, local dof) of the rank's dofs, ascending
+   int LocalDof(int64_t g) const;               // -1: not a dof of this rank
    Array<int> shr_ltdof, ext_ldof, unq_ltdof, unq_shr_i, unq_shr_j;
    std::vector<int> up_ranks, up_sizes, lo_ranks, lo_sizes;
    mfem_amd_exchange *exchange = nullptr;
@@ -1237,14 +1247,14 @@ public:
    ~ParFiniteElementSpace();
    ParMesh *GetParMesh() const { return pmesh; }
    MPI_Comm GetComm() const { return pmesh->GetComm(); }
-   HYPRE_BigInt GlobalTrueVSize() const { return gfes->GetVSize(); }
-   HYPRE_BigInt GlobalVSize() const { return gfes->GetVSize(); }
+   HYPRE_BigInt GlobalTrueVSize() const { return global_ndofs*GetVDim(); }
+   HYPRE_BigInt GlobalVSize() const { return global_ndofs*GetVDim(); }
    int GetTrueVSize() const { return GetVSize(); }
    int GetNOwned() const { return n_owned; }
-   const Array<int> &LocalToGlobal() const { return l2g; }
+   const std::vector<int64_t> &LocalToGlobal() const { return l2g64; }
    const Array<int> &GhostDofs() const { return ext_ldof; }
-   /// fem/pfespace.cpp GetEssentialTrueDofs: the marker is synchronised over the sharing ranks there; here it is
-   /// taken from the serial space, which every rank holds.  Ghost copies of essential dofs are in the list too.
+   /// fem/pfespace.cpp GetEssentialTrueDofs: the marker is synchronised over the sharing ranks there; here every rank
+   /// walks the serial mesh's boundary elements that touch its vertices.  Ghost copies of essential dofs are in the list too.
    void GetEssentialTrueDofs(const Array<int> &bdr_attr_is_ess, Array<int> &ess_tdof_list, int component = -1) const;
    const mfem_amd_comm *Comm() const { return &cb; }
    void Forward(Vector &v) const;               // P: ghosts := owner values

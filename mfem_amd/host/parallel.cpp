@@ -140,62 +140,103 @@ ParFiniteElementSpace::ParFiniteElementSpace(ParMesh *pm, const FiniteElementCol
    : FiniteElementSpace(pm, fec_, vdim_, ordering_), pmesh(pm)
 {
    std::memset(&cb, 0, sizeof cb);
-   gfes = new FiniteElementSpace(const_cast<Mesh*>(&pm->SerialMesh()), fec_, vdim_, ordering_);
    BuildSharedTables();
 }
 ParFiniteElementSpace::~ParFiniteElementSpace()
 {
    if (exchange) { mfem_amd_exchange_destroy(exchange); }
-   delete gfes;
 }
 
-// Ownership and the exchange lists from the serial space's element->dof table and the partition (the same on every
-// rank): a dof's group = the ranks whose elements touch it, its owner = the lowest of them
-// (general/communication.cpp:120-124); lists per neighbour in ascending global dof id on both sides.
+int ParFiniteElementSpace::LocalDof(int64_t g) const
+{
+   auto it = std::lower_bound(g2l.begin(), g2l.end(), std::make_pair(g, -1));
+   return (it != g2l.end() && it->first == g) ? it->second : -1;
+}
+
+// Ownership and the exchange lists from the serial mesh and the partition (the same on every rank): a dof's group = the
+// ranks whose elements touch it, its owner = the lowest of them (general/communication.cpp:120-124); lists per neighbour
+// in ascending global dof id on both sides.  The serial SPACE is never built: its numbering is evaluated element by
+// element (FiniteElementSpace::ElementDofsOf) for the rank's own elements and for the elements of other ranks that share a
+// vertex with them -- every element that touches one of the rank's dofs is among those -- so the work and the memory
+// beyond the serial mesh itself are those of the rank's part and its surface, whatever the number of ranks.
 void ParFiniteElementSpace::BuildSharedTables()
 {
    const int me = pmesh->GetMyRank();
+   const Mesh &sm = pmesh->SerialMesh();
+   const H1_FECollection *h1c = dynamic_cast<const H1_FECollection*>(FEColl());
+   MFEM_VERIFY(h1c, "mfem_amd: only H1_FECollection spaces");
    const std::vector<int> &part = pmesh->Partitioning(), &lel = pmesh->LocalElements();
-   const int nd = GetTypicalFE()->GetDof(), gne = gfes->GetNE(), gnd = gfes->GetNDofs(), nl = GetNDofs();
+   const int nd = GetTypicalFE()->GetDof(), gne = sm.GetNE(), nl = GetNDofs();
+   global_ndofs = FiniteElementSpace::NDofsOf(sm, h1c->GetOrder());
    // local -> global: the j-th dof of an element is the same node in both numberings
-   l2g.SetSize(nl);
-   int *lg = l2g.HostWrite();
-   for (int i = 0; i < nl; i++) { lg[i] = -1; }
+   l2g64.assign((size_t)nl, -1);
+   std::vector<int64_t> gd((size_t)nd);
    for (size_t le = 0; le < lel.size(); le++)
    {
-      const int *ld = ElementDofs((int)le), *gd = gfes->ElementDofs(lel[le]);
-      for (int j = 0; j < nd; j++) { lg[ld[j]] = gd[j]; }
+      const int *ld = ElementDofs((int)le);
+      FiniteElementSpace::ElementDofsOf(sm, *h1c, lel[le], gd.data());
+      for (int j = 0; j < nd; j++) { l2g64[(size_t)ld[j]] = gd[(size_t)j]; }
    }
-   std::vector<int> g2l((size_t)gnd, -1), owner((size_t)gnd, std::numeric_limits<int>::max());
-   for (int i = 0; i < nl; i++) { MFEM_VERIFY(lg[i] >= 0, "local dof without an element"); g2l[(size_t)lg[i]] = i; }
+   for (int i = 0; i < nl; i++) { MFEM_VERIFY(l2g64[(size_t)i] >= 0, "local dof without an element"); }
+   // global -> local, for the dofs that can be shared at all: those of the rank's interface elements (the local elements
+   // after the first InteriorElements(): a dof another rank touches lies on an entity whose vertices that rank touches)
+   g2l.clear();
+   for (int le = pmesh->InteriorElements(); le < (int)lel.size(); le++)
+   {
+      const int *ld = ElementDofs(le);
+      for (int j = 0; j < nd; j++) { g2l.emplace_back(l2g64[(size_t)ld[j]], ld[j]); }
+   }
+   std::sort(g2l.begin(), g2l.end());
+   g2l.erase(std::unique(g2l.begin(), g2l.end()), g2l.end());
+   // the elements of other ranks around the rank's part
+   std::vector<char> mine((size_t)sm.GetNV(), 0);
+   for (int e : lel) { for (int k = 0; k < 8; k++) { mine[(size_t)sm.GetElementVertices(e)[k]] = 1; } }
+   std::vector<int> halo;
    for (int e = 0; e < gne; e++)
    {
-      const int r = part[(size_t)e], *gd = gfes->ElementDofs(e);
-      for (int j = 0; j < nd; j++) { if (r < owner[(size_t)gd[j]]) { owner[(size_t)gd[j]] = r; } }
+      if (part[(size_t)e] == me) { continue; }
+      const int *v = sm.GetElementVertices(e);
+      bool near = false;
+      for (int k = 0; k < 8; k++) { near = near || mine[(size_t)v[k]]; }
+      if (near) { halo.push_back(e); }
    }
-   // upper: (sharing rank, global dof) for the dofs I own that other ranks touch; lower: my ghosts by owner
-   std::vector<std::pair<int, int>> up, lo;
-   for (int e = 0; e < gne; e++)
+   std::vector<int> owner((size_t)nl, me);
+   for (int e : halo)
    {
       const int r = part[(size_t)e];
-      if (r == me) { continue; }
-      const int *gd = gfes->ElementDofs(e);
-      for (int j = 0; j < nd; j++) { if (owner[(size_t)gd[j]] == me) { up.emplace_back(r, gd[j]); } }
+      FiniteElementSpace::ElementDofsOf(sm, *h1c, e, gd.data());
+      for (int j = 0; j < nd; j++)
+      {
+         const int li = LocalDof(gd[(size_t)j]);
+         if (li >= 0 && r < owner[(size_t)li]) { owner[(size_t)li] = r; }
+      }
+   }
+   // upper: (sharing rank, global dof) for the dofs I own that other ranks touch; lower: my ghosts by owner
+   std::vector<std::pair<int, int64_t>> up, lo;
+   for (int e : halo)
+   {
+      const int r = part[(size_t)e];
+      FiniteElementSpace::ElementDofsOf(sm, *h1c, e, gd.data());
+      for (int j = 0; j < nd; j++)
+      {
+         const int li = LocalDof(gd[(size_t)j]);
+         if (li >= 0 && owner[(size_t)li] == me) { up.emplace_back(r, gd[(size_t)j]); }
+      }
    }
    std::sort(up.begin(), up.end());
    up.erase(std::unique(up.begin(), up.end()), up.end());
    n_owned = 0;
    for (int i = 0; i < nl; i++)
    {
-      const int o = owner[(size_t)lg[i]];
+      const int o = owner[(size_t)i];
       if (o == me) { n_owned += GetVDim(); }
-      else { lo.emplace_back(o, lg[i]); }
+      else { lo.emplace_back(o, l2g64[(size_t)i]); }
    }
    std::sort(lo.begin(), lo.end());
    // vector spaces (fem/pfespace.cpp:5266-5345 builds its tables on vdofs): every shared dof carries its vd components,
    // next to each other in the messages, at the vdofs the space's ordering gives them
    const int vd = GetVDim();
-   auto flatten = [&](const std::vector<std::pair<int, int>> &prs, std::vector<int> &ranks, std::vector<int> &sizes, Array<int> &ids)
+   auto flatten = [&](const std::vector<std::pair<int, int64_t>> &prs, std::vector<int> &ranks, std::vector<int> &sizes, Array<int> &ids)
    {
       ranks.clear(); sizes.clear();
       ids.SetSize((int)prs.size()*vd);
@@ -204,7 +245,7 @@ void ParFiniteElementSpace::BuildSharedTables()
       {
          if (ranks.empty() || ranks.back() != prs[k].first) { ranks.push_back(prs[k].first); sizes.push_back(0); }
          sizes.back() += vd;
-         for (int c = 0; c < vd; c++) { p[k*vd + c] = DofToVDof(g2l[(size_t)prs[k].second], c); }
+         for (int c = 0; c < vd; c++) { p[k*vd + c] = DofToVDof(LocalDof(prs[k].second), c); }
       }
    };
    flatten(up, up_ranks, up_sizes, shr_ltdof);
@@ -238,21 +279,39 @@ void ParFiniteElementSpace::BuildSharedTables()
 
 void ParFiniteElementSpace::GetEssentialTrueDofs(const Array<int> &bdr_attr_is_ess, Array<int> &ess_tdof_list, int component) const
 {
-   // the serial mesh's boundary attributes: a marker sized for the local mesh may be shorter
+   // the boundary elements of the rank's own elements (the local mesh has them), and -- a local dof on the domain boundary may
+   // lie on boundary faces of other ranks' elements only -- the serial mesh's boundary elements that touch a vertex of the
+   // rank's part, numbered as the serial space numbers them and looked up among the rank's interface dofs; ascending vdofs
    const Mesh &sm = pmesh->SerialMesh();
-   Array<int> gmarker(sm.bdr_attributes.Size() ? sm.bdr_attributes.Max() : 0);
-   gmarker = 0;
-   for (int i = 0; i < gmarker.Size() && i < bdr_attr_is_ess.Size(); i++) { gmarker[i] = bdr_attr_is_ess[i]; }
-   Array<int> gess;
-   if (gmarker.Size()) { gfes->GetEssentialVDofs(gmarker, gess, component); }
-   // local vdof (i, c) <-> global vdof (l2g[i], c), each in its own space's ordering; the list ascends in local vdofs
-   const int nl = GetNDofs(), vd = GetVDim();
+   const H1_FECollection *h1c = dynamic_cast<const H1_FECollection*>(FEColl());
+   const int vd = GetVDim(), ne1 = h1c->GetOrder() - 1, nbd = 4 + 4*ne1 + ne1*ne1;
+   Array<int> marker;
+   FiniteElementSpace::GetEssentialVDofs(bdr_attr_is_ess, marker, component);
    std::vector<int> list;
-   for (int i = 0; gess.Size() && i < nl; i++)
+   for (int i = 0; i < marker.Size(); i++) { if (marker[i]) { list.push_back(i); } }
+   std::vector<char> mine((size_t)sm.GetNV(), 0);
+   for (int e : pmesh->LocalElements()) { for (int k = 0; k < 8; k++) { mine[(size_t)sm.GetElementVertices(e)[k]] = 1; } }
+   std::vector<int64_t> bd((size_t)nbd);
+   for (int b = 0; b < sm.GetNBE(); b++)
    {
-      for (int c = 0; c < vd; c++) { if (gess[gfes->DofToVDof(l2g[i], c)]) { list.push_back(DofToVDof(i, c)); } }
+      const int attr = sm.GetBdrAttribute(b);
+      if (attr < 1 || attr > bdr_attr_is_ess.Size() || !bdr_attr_is_ess[attr - 1]) { continue; }
+      const int *v = sm.GetBdrElementVertices(b);
+      const int nmine = mine[(size_t)v[0]] + mine[(size_t)v[1]] + mine[(size_t)v[2]] + mine[(size_t)v[3]];
+      if (nmine == 0) { continue; }
+      const int f = sm.GetBdrElementFaceIndex(b), e1 = sm.GetFaceElement1(f);
+      if (e1 >= 0 && pmesh->Partitioning()[(size_t)e1] == pmesh->GetMyRank()) { continue; }     // the local mesh has it
+      FiniteElementSpace::BdrElementDofsOf(sm, *h1c, b, bd.data());
+      for (int i = 0; i < nbd; i++)
+      {
+         const int li = LocalDof(bd[(size_t)i]);
+         if (li < 0) { continue; }
+         if (component < 0) { for (int c = 0; c < vd; c++) { list.push_back(DofToVDof(li, c)); } }
+         else { list.push_back(DofToVDof(li, component)); }
+      }
    }
    std::sort(list.begin(), list.end());
+   list.erase(std::unique(list.begin(), list.end()), list.end());
    ess_tdof_list.SetSize((int)list.size());
    for (size_t k = 0; k < list.size(); k++) { ess_tdof_list[(int)k] = list[k]; }
 }
