@@ -50,7 +50,8 @@ constexpr int minw_for(int KIND, int D, int PF = 0, int RB = 1, bool VEC = false
 // Staged stores (kernel comment at the copy-out): which specialisations send their packed E-vector entries and interior rows
 // through LDS and out as whole lines.  Measured A/B on one box, whole apply at 1e7 dofs on the reference's numbering
 // (profiles/r3/staged_stores_ab.txt): BP1 p = 2..7 +1.3..4.0 %, p = 8 -1.4 %; BP3 p = 2 +0.8, p = 3 -1.5, p = 4 +2.5, p = 5, 6
-// +0.3 / 0, p = 7 -1.0, p = 8 +0.9 %; BP5 p = 2, 3 -0.6 / -3.5, p = 4..7 +0.8 / 3.3 / 3.8 / 0.5, p = 8 -4.7 %.
+// +0.3 / 0, p = 7 -1.0, p = 8 +0.9 %; BP5 p = 2, 3 -0.6 / -3.5, p = 4..7 +0.8 / 3.3 / 3.8 / 0.5, p = 8 -4.7 %; D = 8 re-measured with
+// the whole-column schedule it got later (staged_stores_ab.txt, end): (8,9) staged 0.279 -> 0.466 ms, (8,8) -1.5 %, mass +3.5 %.
 // MFA_STAGE_STORE=0 | 1 (build) forces it off / on everywhere.
 #ifndef MFA_STAGE_STORE
 #define MFA_STAGE_STORE -1
@@ -59,7 +60,7 @@ constexpr bool stage_store_for(int KIND, int D, int Q)
 {
    if (MFA_STAGE_STORE >= 0) { return MFA_STAGE_STORE != 0; }
    if (KIND == 0) { return D <= 8; }
-   if (Q == D) { return D >= 5 && D <= 8; }
+   if (Q == D) { return D >= 5 && D <= 7; }     // ((8,8) with its round-3 schedule -- whole columns, one batch per workgroup: direct stores 1-2 % faster)
    return D != 4 && D != 8;
 }
 
@@ -1173,7 +1174,9 @@ static int apply_mode(int KIND, int D, int Q)
    // the persistent round-robin schedule wins where registers allow one wave per SIMD only
    // ((6,6) was persistent with streamed pa_data after round 1's isolated sweep; in the alternating apply the plain
    // form is 2 % faster: profiles/r2/ctx_sweep_bp5.txt)
-   return (KIND == 1 && (D >= 9 || (D == 8 && Q == 8))) ? 2 : 0;
+   // ((8,8) too until the re-sweep on the final tree of round 3 -- staged stores, packed E-vector: one batch per workgroup with
+   // whole columns is 6 % faster there now, profiles/r3/ctx_sweep_final.txt)
+   return (KIND == 1 && D >= 9) ? 2 : 0;
 }
 
 typedef int (*apply_fn)(int64_t ne, const double *B, const double *G, const double *Dq,
@@ -1196,7 +1199,8 @@ static int apply_pf(int KIND, int D, int Q)
    if (KIND == 1)
    {
       if (D >= 9) { return Q == D ? 3 : 2; }
-      if (D == 8) { return 2; }
+      // (D = 8 streamed two slices until round 3's re-sweep in context: with the packed E-vector and the staged stores the
+      // whole-column, non-temporal form is 6-7 % faster at (8,9) and (8,8), profiles/r3/ctx_sweep_final.txt)
       if (D == 5 && Q == 8) { return 2; }        // eight whole z-slices do not fit three waves' registers (40-92 B of scratch)
    }
    return 0;
@@ -1205,8 +1209,8 @@ static int apply_pf(int KIND, int D, int Q)
 constexpr int rb_table(int KIND, int D, int Q)
 {
    if (KIND == 0) { return D >= 4 ? 2 : 1; }
-   if (Q == D) { return (D == 5 || D == 6 || D >= 8) ? 2 : 1; }
-   return D >= 8 ? 2 : (D >= 4 ? 1 : 0);
+   if (Q == D) { return (D == 5 || D == 6 || D >= 9) ? 2 : 1; }
+   return D >= 9 ? 2 : (D >= 4 ? 1 : 0);
 }
 
 // register-blocked contractions (kernel comment): MFEM_AMD_APPLY_RB=0|1|2 overrides (tuning aid)
