@@ -109,6 +109,12 @@ constexpr bool stage_store_for(int KIND, int D, int Q)
 #ifndef MFA_SPLIT_O
 #define MFA_SPLIT_O 1
 #endif
+#ifndef MFA_ONE_TRIP
+#define MFA_ONE_TRIP 1
+#endif
+#ifndef MFA_O_EARLY
+#define MFA_O_EARLY 0
+#endif
 #ifndef MFA_STAGE_W16
 #define MFA_STAGE_W16 -1
 #endif
@@ -221,9 +227,15 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
       if (bid < (G_/per)*per) { L = ((bid/per)*8 + (bid & 7))*sched + ((bid >> 3) % sched); }
    }
    const int64_t b0 = SCHED ? L : (L*nbatches)/G_;
-   const int64_t b1 = SCHED ? nbatches : ((L + 1)*nbatches)/G_;
-   const int64_t bstep = SCHED ? G_ : 1;
-   if (b0 >= b1) { return; }              // uniform over the workgroup, before any barrier
+   // One batch per workgroup: a trip count the compiler can see (MFA_ONE_TRIP).  As a loop over [b0, nbatches) in steps of
+   // the grid size -- one trip at run time, unknown at compile time -- the body "contains stores, no loads, and uses values
+   // loaded outside", and for such a loop the compiler drains every outstanding load in the preheader (s_waitcnt vmcnt(0)):
+   // the whole pa_data column had to land before the x values could even be staged.  Without the loop the waits are
+   // counted: the x / y contractions run while pa_data is still arriving, and the z loop starts on its first slices.
+   constexpr bool ONE = !PERSIST && MFA_ONE_TRIP;
+   const int64_t b1 = ONE ? b0 + 1 : (SCHED ? nbatches : ((L + 1)*nbatches)/G_);
+   const int64_t bstep = ONE ? 1 : (SCHED ? G_ : 1);
+   if (b0 >= (ONE ? nbatches : b1)) { return; }              // uniform over the workgroup, before any barrier
 
    double *sA = smem[tz];
    double *sV = sA + SA;
@@ -315,8 +327,10 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
          }
          else if (GATHER)
          {
+            // (one batch per workgroup: the mask is applied when the value is staged -- here it would wait for the value
+            // in the middle of the pa_data requests)
             const double v = x[gi[k] >= 0 ? gi[k] : 0];
-            xv[k] = gi[k] >= 0 ? v : 0.0;
+            xv[k] = (ONE || gi[k] >= 0) ? v : 0.0;
          }
          else { xv[k] = xe[i < D3 ? i : D3 - 1]; }
       }
@@ -397,8 +411,11 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
 #pragma unroll
       for (int k = 0; k < NXV; k++)
       {
-         const int i = t2 + k*QQ;
-         if (i < D3) { sX[RB ? (i/D)*DP + i % D : i] = xv[k]; }
+         // unconditional: a thread past the end holds the LAST entry's value (the loaders clamp the same way) and writes it
+         // where its owner does.  Behind an `if` the compiler sinks that request to the store -- below the pa_data stream,
+         // and drains the stream there (s_waitcnt vmcnt(0)) -- once loads and store share a block (MFA_ONE_TRIP)
+         const int i = (t2 + k*QQ < D3) ? t2 + k*QQ : D3 - 1;
+         sX[RB ? (i/D)*DP + i % D : i] = (ONE && GATHER && !VEC && gi[k] < 0) ? 0.0 : xv[k];
       }
    };
    // One batch per workgroup, whole pa_data columns in registers: the x values can be staged between the two halves of the
@@ -411,14 +428,21 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
    {
       const int64_t e = b0*NBZ + tz;
       load_gi(e);
+      // tuning builds (-DMFA_O_EARLY=<slices>, < 0: all): request that many z-slices of pa_data BEFORE the gather waits for
+      // its indices, so that the index latency of a one-batch workgroup is not spent with nothing in flight
+      constexpr int OE = (!PERSIST && PF == 0 && !SPLIT && !VEC && ABL == 0 && BLK && GATHER) ? (MFA_O_EARLY < 0 || MFA_O_EARLY > Q ? Q : MFA_O_EARLY) : 0;
+      if (OE > 0) { load_O(e, b0, 0, OE); }
       load_xv(e);
       if (SPLIT) { load_O(e, b0, 0, Q/2); stage_x(); load_O(e, b0, Q/2, Q); }
-      else if (PF == 0) { load_O(e, b0); }
+      else if (PF == 0) { load_O(e, b0, OE, Q); }
       else
       {
 #pragma unroll
          for (int s = 0; s < PF; s++) { load_slice(b0, s, O[s]); }
       }
+      // (with the body in the same block as these requests the scheduler would sink some of them to their first use --
+      // behind the pa_data stream, and wait for all of it there)
+      if (ONE) { __builtin_amdgcn_sched_barrier(0); }
    }
 
    for (int64_t bt = b0; bt < b1; bt += bstep)
