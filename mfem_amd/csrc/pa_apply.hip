@@ -109,6 +109,21 @@ constexpr bool stage_store_for(int KIND, int D, int Q)
 #ifndef MFA_SPLIT_O
 #define MFA_SPLIT_O 1
 #endif
+// In-place transposed y contraction (diffusion, RB = 1, one batch per workgroup; kernel comment at INPL): which
+// specialisations drop LDS region V.  It pays where LDS was what limited the resident workgroups and the registers allow one
+// more (profiles/r3/inplace_ab.txt, whole apply at 1e7 dofs): (6,7) 2 -> 3 workgroups per CU, BP3 p = 5 0.611 -> 0.643;
+// (6,6) 0.602 -> 0.639 (with RB 1 instead of 2), (7,7) 0.599 -> 0.639, (8,8) 3 -> 4 workgroups, 0.615 -> 0.652.  Where the
+// registers are the limit anyway it only adds bank conflicts to the last phase's row reads: (7,8) 0.665 -> 0.649, (5,5) with
+// RB 1 0.577 -> 0.570, (5,6) / (4,5) / (8,9) +-0.  MFA_INPLACE=0 | 1 (build) forces it off / on for every eligible kernel.
+#ifndef MFA_INPLACE
+#define MFA_INPLACE -1
+#endif
+constexpr bool inplace_for(int D, int Q)
+{
+   if (MFA_INPLACE >= 0) { return MFA_INPLACE != 0; }
+   if (Q == D) { return D >= 6 && D <= 8; }
+   return D == 6 && Q == 7;
+}
 #ifndef MFA_ONE_TRIP
 #define MFA_ONE_TRIP 1
 #endif
@@ -205,7 +220,16 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
    constexpr int SA = (SA1 > NF*DQQ) ? SA1 : NF*DQQ;
    constexpr int SV = NX*DDQ;
    constexpr int NXV = (D3 + QQ - 1)/QQ;  // x values staged per thread
-   __shared__ double smem[NBZ][SA + SV];
+   // INPL: thread (qx,dz) of the transposed y contraction reads its three columns of sT (region A) and nobody else's, and it
+   // has read them all before it stores: its D outputs per field can go where the first D of its Q inputs were, and region V
+   // is not needed at all (RB = 1 keeps the x-contracted fields in region A as well) -- a third less LDS per element, one
+   // more resident workgroup where LDS was the limit.  The third field's planes are dead by the last phase: the staged
+   // stores use them.  One batch per workgroup only (no next batch whose x values would land on region A's last readers).
+   constexpr bool INPL = KIND == 1 && RB == 1 && !PERSIST && MFA_ONE_TRIP && !VEC && ABL == 0 && inplace_for(D, Q);
+   constexpr int ESTRIDE = SA + (INPL ? 0 : SV);      // doubles of LDS per element
+   constexpr int STGO = INPL ? 2*DQQ : 0;             // where the staged stores collect an element's values
+   static_assert(!INPL || STGO + D3 <= SA, "staging area inside the third field's planes");
+   __shared__ double smem[NBZ][ESTRIDE];
    __shared__ double sB[Q*D], sG[Q*D];
 
    const int a = threadIdx.x, b = threadIdx.y, tz = threadIdx.z;
@@ -762,8 +786,12 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
 #pragma unroll
                for (int dy = 0; dy < D; dy++)
                {
-                  sV[(dz*D + dy)*QP + qx] = v23[dy];
-                  if (KIND) { sV[DDQ + (dz*D + dy)*QP + qx] = v1[dy]; }
+                  if (INPL) { sT[tix(dz, dy, qx)] = v23[dy]; sT[tix(D + dz, dy, qx)] = v1[dy]; }
+                  else
+                  {
+                     sV[(dz*D + dy)*QP + qx] = v23[dy];
+                     if (KIND) { sV[DDQ + (dz*D + dy)*QP + qx] = v1[dy]; }
+                  }
                }
             }
          }
@@ -801,7 +829,11 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
             {
                double V23[Q], V1[Q];
 #pragma unroll
-               for (int qx = 0; qx < Q; qx++) { V23[qx] = sV[t2*QP + qx]; V1[qx] = KIND ? sV[DDQ + t2*QP + qx] : 0.0; }
+               for (int qx = 0; qx < Q; qx++)
+               {
+                  if (INPL) { V23[qx] = sT[tix(t2/D, t2 % D, qx)]; V1[qx] = sT[tix(D + t2/D, t2 % D, qx)]; }
+                  else { V23[qx] = sV[t2*QP + qx]; V1[qx] = KIND ? sV[DDQ + t2*QP + qx] : 0.0; }
+               }
                double yv[D];
 #pragma unroll
                for (int dx = 0; dx < D; dx++)
@@ -830,7 +862,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
                   const int code = sTab[t2];
                   const int p0 = code & 1023, dl = (code >> 10) & 1023, pm = ((code >> 20) & 1023) + (((code >> 30) & 1) ? NSP : 0);
 #pragma unroll
-                  for (int dx = 0; dx < D; dx++) { sA[dx == 0 ? p0 : (dx == D - 1 ? p0 + dl : pm + dx - 1)] = yv[dx]; }
+                  for (int dx = 0; dx < D; dx++) { sA[STGO + (dx == 0 ? p0 : (dx == D - 1 ? p0 + dl : pm + dx - 1))] = yv[dx]; }
                }
                else if (DIRECT && va.ydirect)
                {
@@ -926,7 +958,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
             // (profiles/r3/store_probe.txt).  From LDS the workgroup's elements leave as two contiguous runs instead: the
             // batch's packed E-vector entries (NBZ*NS doubles) and its interior rows of y (NBZ*(D-2)^3), whole lines per
             // wave instruction.  Same values at the same addresses.
-            constexpr int NSP = packed_size(D), NIP = D3 - NSP, STRIDE = SA + SV, NT = QQ*NBZ;
+            constexpr int NSP = packed_size(D), NIP = D3 - NSP, STRIDE = ESTRIDE, NT = QQ*NBZ;
             __syncthreads();
             // (an opaque copy of the thread's index: everything the copy-out derives from it is formed here, after the z loop,
             // instead of being hoisted above it, where the (5,6) kernel has no register to spare)
@@ -940,7 +972,7 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
             auto copy_out = [&](double *dst, const int n, auto per_c, auto off_c)
             {
                constexpr int per = decltype(per_c)::value, off = decltype(off_c)::value;
-               auto at = [&](const int i) { const int ee = i/per; return sm[ee*STRIDE + off + (i - ee*per)]; };
+               auto at = [&](const int i) { const int ee = i/per; return sm[ee*STRIDE + STGO + off + (i - ee*per)]; };
                if (!STG16)
                {
 #pragma unroll
@@ -1233,7 +1265,7 @@ static int apply_pf(int KIND, int D, int Q)
 constexpr int rb_table(int KIND, int D, int Q)
 {
    if (KIND == 0) { return D >= 4 ? 2 : 1; }
-   if (Q == D) { return (D == 5 || D == 6 || D >= 9) ? 2 : 1; }
+   if (Q == D) { return (D == 5 || D >= 9) ? 2 : 1; }       // ((6,6): level 1 since it can contract in place, inplace_for)
    return D >= 9 ? 2 : (D >= 4 ? 1 : 0);
 }
 

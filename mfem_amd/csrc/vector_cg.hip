@@ -119,6 +119,9 @@ k_mul(const int64_t n, const double *__restrict__ a, const double *__restrict__ 
    }
 }
 
+#ifndef MFA_PCG_UNROLL
+#define MFA_PCG_UNROLL 2
+#endif
 // ---- device-resident PCG state -------------------------------------------------------
 struct PcgState
 {
@@ -235,7 +238,30 @@ k_pcg_update(const int64_t n, const PcgState *__restrict__ st, const double *__r
    if (st->done) { return; }
    const double alpha = st->alpha;
    double acc = 0.0;
-   for (int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x; i < n; i += (int64_t)gridDim.x*256)
+   // U grid strides per trip, every load of the trip requested before the first value is used (the plain loop keeps one
+   // element per thread in flight: load, wait, store).  Same elements per thread in the same order: same partial sums.
+   constexpr int U = MFA_PCG_UNROLL;
+   const int64_t stride = (int64_t)gridDim.x*256;
+   int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x;
+   for (; i + (U - 1)*stride < n; i += U*stride)
+   {
+      double rr[U], zz[U], dd[U];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+      {
+         rr[u] = ld_stream<NT>(&r[i + u*stride]); zz[u] = z[i + u*stride];
+         dd[u] = dinv ? ld_stream<NT>(&dinv[i + u*stride]) : 1.0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++)
+      {
+         const double ri = rr[u] + (-alpha)*zz[u];
+         const double zi = dinv ? dd[u]*ri : ri;
+         st_stream<NT>(&r[i + u*stride], ri); z[i + u*stride] = zi;
+         acc += ri*zi;
+      }
+   }
+   for (; i < n; i += stride)
    {
       const double ri = ld_stream<NT>(&r[i]) + (-alpha)*z[i];
       const double zi = dinv ? ld_stream<NT>(&dinv[i])*ri : ri;
@@ -276,7 +302,25 @@ k_pcg_dir(const int64_t n, const PcgState *__restrict__ st, const double *__rest
       }
       return;
    }
-   for (int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x; i < n; i += (int64_t)gridDim.x*256)
+   constexpr int U = MFA_PCG_UNROLL;                  // (as in kernel A)
+   const int64_t stride = (int64_t)gridDim.x*256;
+   int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x;
+   for (; i + (U - 1)*stride < n; i += U*stride)
+   {
+      double dd[U], xx[U], zz[U];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+      {
+         dd[u] = d[i + u*stride]; xx[u] = ld_stream<NT>(&x[i + u*stride]); zz[u] = ld_stream<NT>(&z[i + u*stride]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++)
+      {
+         st_stream<NT>(&x[i + u*stride], xx[u] + alpha*dd[u]);
+         d[i + u*stride] = zz[u] + beta*dd[u];
+      }
+   }
+   for (; i < n; i += stride)
    {
       const double di = d[i];
       st_stream<NT>(&x[i], ld_stream<NT>(&x[i]) + alpha*di);
