@@ -1232,7 +1232,10 @@ static int apply_mode(int KIND, int D, int Q)
    // form is 2 % faster: profiles/r2/ctx_sweep_bp5.txt)
    // ((8,8) too until the re-sweep on the final tree of round 3 -- staged stores, packed E-vector: one batch per workgroup with
    // whole columns is 6 % faster there now, profiles/r3/ctx_sweep_final.txt)
-   return (KIND == 1 && D >= 9) ? 2 : 0;
+   // ((9,10) too once the one-batch form lost its one-trip loop: whole columns fit 248 VGPRs without the loop-carried
+   // addresses -- 258 us against 296 for the persistent streamed form, profiles/r3/ctx_sweep_one_trip.txt; (9,9) stays
+   // persistent, 262 against 297)
+   return (KIND == 1 && D >= 9 && Q == D) ? 2 : 0;
 }
 
 typedef int (*apply_fn)(int64_t ne, const double *B, const double *G, const double *Dq,
@@ -1254,7 +1257,7 @@ static int apply_pf(int KIND, int D, int Q)
    // collocated (Q = D) kernels at p = 5, 7, 8; everywhere else holding the column is as fast or faster
    if (KIND == 1)
    {
-      if (D >= 9) { return Q == D ? 3 : 2; }
+      if (D >= 9) { return Q == D ? 3 : 0; }
       // (D = 8 streamed two slices until round 3's re-sweep in context: with the packed E-vector and the staged stores the
       // whole-column, non-temporal form is 6-7 % faster at (8,9) and (8,8), profiles/r3/ctx_sweep_final.txt)
       if (D == 5 && Q == 8) { return 2; }        // eight whole z-slices do not fit three waves' registers (40-92 B of scratch)
@@ -1266,7 +1269,8 @@ constexpr int rb_table(int KIND, int D, int Q)
 {
    if (KIND == 0) { return D >= 4 ? 2 : 1; }
    if (Q == D) { return (D == 5 || D >= 9) ? 2 : 1; }       // ((6,6): level 1 since it can contract in place, inplace_for)
-   return D >= 9 ? 2 : (D >= 4 ? 1 : 0);
+   // ((3,4): level 2 holds 91 VGPRs, five workgroups per CU instead of four: 950 against 964 us, rb_resweep_one_trip.txt)
+   return D >= 9 ? 2 : (D >= 4 ? 1 : (D == 3 && Q == 4 ? 2 : 0));
 }
 
 // register-blocked contractions (kernel comment): MFEM_AMD_APPLY_RB=0|1|2 overrides (tuning aid)
