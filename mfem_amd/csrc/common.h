@@ -41,6 +41,9 @@ struct BasisTT
 // otherwise; halving the other sizes was equal or slower, profiles/r1/sweep_nbz_half.txt).
 // Also the blocking factor of the HBM-friendly pa_data layout below.
 // (MFA_NBZ<Q>: tuning overrides -- every source file must see the same values.)
+#ifndef MFA_NBZ3
+#define MFA_NBZ3 16
+#endif
 #ifndef MFA_NBZ4
 #define MFA_NBZ4 16
 #endif
@@ -58,7 +61,7 @@ struct BasisTT
 #endif
 __host__ __device__ constexpr int nbz_for(int Q)
 {
-   return Q <= 2 ? 32 : Q == 3 ? 16 : Q == 4 ? MFA_NBZ4 : Q == 5 ? MFA_NBZ5 : Q == 6 ? MFA_NBZ6 :
+   return Q <= 2 ? 32 : Q == 3 ? MFA_NBZ3 : Q == 4 ? MFA_NBZ4 : Q == 5 ? MFA_NBZ5 : Q == 6 ? MFA_NBZ6 :
           Q == 7 ? MFA_NBZ7 : Q == 8 ? MFA_NBZ8 : Q == 9 ? 3 : 2;
 }
 

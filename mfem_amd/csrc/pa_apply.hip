@@ -121,7 +121,7 @@ constexpr bool stage_store_for(int KIND, int D, int Q)
 constexpr bool inplace_for(int D, int Q)
 {
    if (MFA_INPLACE >= 0) { return MFA_INPLACE != 0; }
-   if (Q == D) { return D >= 6 && D <= 8; }
+   if (Q == D) { return D >= 6; }        // ((9,9): 89 -> 54 KB, 1 -> 2 workgroups per CU: 263 -> 206 us, BP5 p = 8 0.48 -> 0.61)
    return D == 6 && Q == 7;
 }
 #ifndef MFA_ONE_TRIP
@@ -200,8 +200,10 @@ k_pa_apply(const int64_t ne, const int64_t nbatches, const int sched, const Basi
    constexpr int NX = KIND ? 2 : 1;       // fields after the x contraction (B x, G x)
    constexpr bool DIRECT = GATHER && !ACCUM && !VEC && ABL == 0 && D >= 3;   // va.ydirect honoured
    constexpr bool STG = DIRECT && stage_store_for(KIND, D, Q);               // ... through LDS, as whole lines
-   // (16 bytes a lane in the copy-out, except where that form costs the kernel a spilled x value: MFA_STAGE_W16 = 0 | 1 forces)
-   constexpr bool STG16 = MFA_STAGE_W16 < 0 ? !(KIND == 1 && D == 5 && Q == 6 && RB == 1) : (MFA_STAGE_W16 != 0);
+   // (16 bytes a lane in the copy-out; MFA_STAGE_W16 = 0 forces 8.  The (5,6) diffusion kernel kept 8-byte lanes while its
+   // looping form had no register to spare -- the wide form cost it a spilled x value; without the loop 16 bytes are 0.25 %
+   // faster there too, profiles/r3/staged_stores_ab.txt, end)
+   constexpr bool STG16 = MFA_STAGE_W16 != 0;
    // LDS strides (doubles): rows that one thread walks (sX, sBX/sGX, sV) are padded to an odd
    // length; the (qy,qx) planes of sT keep dense rows and get a small pad as a whole for even Q.
    // (Measured: padding or transposing the planes so that the row-per-thread reads are entirely
@@ -1234,8 +1236,9 @@ static int apply_mode(int KIND, int D, int Q)
    // whole columns is 6 % faster there now, profiles/r3/ctx_sweep_final.txt)
    // ((9,10) too once the one-batch form lost its one-trip loop: whole columns fit 248 VGPRs without the loop-carried
    // addresses -- 258 us against 296 for the persistent streamed form, profiles/r3/ctx_sweep_one_trip.txt; (9,9) stays
-   // persistent, 262 against 297)
-   return (KIND == 1 && D >= 9 && Q == D) ? 2 : 0;
+   // persistent, 262 against 297 -- until it could contract in place, inplace_for: 206 us in the one-batch form).  Every
+   // dispatched kernel is a one-batch-per-workgroup kernel now; the persistent forms stay behind the override.
+   return 0;
 }
 
 typedef int (*apply_fn)(int64_t ne, const double *B, const double *G, const double *Dq,
@@ -1257,7 +1260,7 @@ static int apply_pf(int KIND, int D, int Q)
    // collocated (Q = D) kernels at p = 5, 7, 8; everywhere else holding the column is as fast or faster
    if (KIND == 1)
    {
-      if (D >= 9) { return Q == D ? 3 : 0; }
+      // (D = 9 streamed two / three slices through the persistent schedule until the one-trip and in-place forms)
       // (D = 8 streamed two slices until round 3's re-sweep in context: with the packed E-vector and the staged stores the
       // whole-column, non-temporal form is 6-7 % faster at (8,9) and (8,8), profiles/r3/ctx_sweep_final.txt)
       if (D == 5 && Q == 8) { return 2; }        // eight whole z-slices do not fit three waves' registers (40-92 B of scratch)
@@ -1268,7 +1271,7 @@ static int apply_pf(int KIND, int D, int Q)
 constexpr int rb_table(int KIND, int D, int Q)
 {
    if (KIND == 0) { return D >= 4 ? 2 : 1; }
-   if (Q == D) { return (D == 5 || D >= 9) ? 2 : 1; }       // ((6,6): level 1 since it can contract in place, inplace_for)
+   if (Q == D) { return D == 5 ? 2 : 1; }       // ((6,6), (9,9): level 1 since they can contract in place, inplace_for)
    // ((3,4): level 2 holds 91 VGPRs, five workgroups per CU instead of four: 950 against 964 us, rb_resweep_one_trip.txt)
    return D >= 9 ? 2 : (D >= 4 ? 1 : (D == 3 && Q == 4 ? 2 : 0));
 }
