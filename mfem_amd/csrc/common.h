@@ -59,8 +59,17 @@ struct BasisTT
 #ifndef MFA_NBZ8
 #define MFA_NBZ8 2
 #endif
-__host__ __device__ constexpr int nbz_for(int Q)
+// (per operator where the two disagree: the mass kernel's Q = 3 batch, profiles/r3/nbz3_probe.txt)
+#ifndef MFA_NBZ3M
+#define MFA_NBZ3M 28
+#endif
+#ifndef MFA_NBZ8M
+#define MFA_NBZ8M MFA_NBZ8
+#endif
+__host__ __device__ constexpr int nbz_for(int kind, int Q)
 {
+   if (kind == 0 && Q == 3) { return MFA_NBZ3M; }
+   if (kind == 0 && Q == 8) { return MFA_NBZ8M; }
    return Q <= 2 ? 32 : Q == 3 ? MFA_NBZ3 : Q == 4 ? MFA_NBZ4 : Q == 5 ? MFA_NBZ5 : Q == 6 ? MFA_NBZ6 :
           Q == 7 ? MFA_NBZ7 : Q == 8 ? MFA_NBZ8 : Q == 9 ? 3 : 2;
 }
@@ -75,7 +84,7 @@ __host__ __device__ constexpr int nbz_for(int Q)
 // not change.
 __host__ __device__ inline int64_t blocked_index(int kind, int Q, int64_t e, int q, int c)
 {
-   const int NBZ = nbz_for(Q), QQ = Q*Q;
+   const int NBZ = nbz_for(kind, Q), QQ = Q*Q;
    const int64_t batch = e/NBZ;
    const int tz = (int)(e % NBZ), qz = q/QQ, qq = q % QQ;
    if (kind) { return ((((batch*Q + qz)*3 + (c >> 1))*NBZ + tz)*QQ + qq)*2 + (c & 1); }
@@ -84,7 +93,7 @@ __host__ __device__ inline int64_t blocked_index(int kind, int Q, int64_t e, int
 
 __host__ __device__ inline int64_t blocked_size(int kind, int Q, int64_t ne)
 {
-   const int NBZ = nbz_for(Q);
+   const int NBZ = nbz_for(kind, Q);
    return ((ne + NBZ - 1)/NBZ)*NBZ*(int64_t)(kind ? 6 : 1)*Q*Q*Q;
 }
 

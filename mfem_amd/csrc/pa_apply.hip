@@ -1309,7 +1309,7 @@ template <int KIND, int D, int Q, bool GATHER, bool ACCUM, bool BLK, int PF = 0,
 static int launch_apply(int64_t ne, const double *B, const double *G, const double *Dq,
                         const double *x, const int *gmap, double *yE, double *ydir, hipStream_t s)
 {
-   constexpr int NBZ = nbz_for(Q);
+   constexpr int NBZ = nbz_for(KIND, Q);
    constexpr bool HOT = BLK && GATHER && !ACCUM && Q > 3;
    if (HOT && !RESOLVED)
    {
@@ -1468,7 +1468,7 @@ template <int KIND, int D, int Q, bool GATHER, bool ACCUM, bool BLK>
 static int launch_apply_vec(int64_t ne, const double *B, const double *G, const double *Dq,
                             const double *x, const int *gmap, double *yE, VecArgs va, hipStream_t s)
 {
-   constexpr int NBZ = nbz_for(Q);
+   constexpr int NBZ = nbz_for(KIND, Q);
    constexpr int RBV = Q > 3 ? rb_table(KIND, D, Q) : 0;
    constexpr bool NTV = BLK && GATHER && !ACCUM;
    const bool nt = NTV && apply_nt((int64_t)sizeof(double)*blocked_size(KIND, Q, ne)*(va.d_comp_stride ? va.vd : 1));

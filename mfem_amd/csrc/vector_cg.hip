@@ -549,8 +549,8 @@ static int constrained_mult(const mfem_amd_pa_operator *op, const mfem_amd_comm 
    static const bool overlap_ok = !(getenv("MFEM_AMD_OVERLAP") && atoi(getenv("MFEM_AMD_OVERLAP")) == 0);
    const bool overlap = comm && overlap_ok && op->e_split > 0 && op->e_split < op->ne;
    MFA_REQUIRE(op->e_split >= 0 && op->e_split <= op->ne, "pa operator: e_split out of range");
-   MFA_REQUIRE(!overlap || !op->pa_layout || op->e_split % nbz_for(op->Q1D) == 0,
-               "pa operator: e_split must be a multiple of the blocked layout's batch (%d elements)", nbz_for(op->Q1D));
+   MFA_REQUIRE(!overlap || !op->pa_layout || op->e_split % nbz_for(op->kind, op->Q1D) == 0,
+               "pa operator: e_split must be a multiple of the blocked layout's batch (%d elements)", nbz_for(op->kind, op->Q1D));
    if (comm && !overlap)
    {
       if (int rc = comm->forward(comm->ctx, x, (void*)s)) { set_error("comm forward exchange failed (%d)", rc); return rc; }
