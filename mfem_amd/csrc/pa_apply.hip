@@ -38,7 +38,10 @@ constexpr int minw_for(int KIND, int D, int PF = 0, int RB = 1, bool VEC = false
 {
    // (5,8): only the dispatched form (two z-slices streamed) fits three waves; the override-only forms get two
    if (KIND && D == 5 && Q >= 8 && PF != 2) { return 2; }
-   if (PF > 0) { return KIND ? (D <= 6 ? 3 : 2) : (D <= 7 ? 4 : 3); }   // streamed pa_data: fewer live registers
+#ifndef MFA_MINW_PF          // (tuning builds: the register budget of the streamed diffusion kernels at D <= 6, in waves per SIMD)
+#define MFA_MINW_PF 3
+#endif
+   if (PF > 0) { return KIND ? (D <= 6 ? MFA_MINW_PF : 2) : (D <= 7 ? 4 : 3); }   // streamed pa_data: fewer live registers
    // D = 5 diffusion fits the 168 VGPRs of three waves per SIMD only in its register-blocked scalar form; the
    // component loop (VEC) and the one-output-per-thread form (RB = 0: MFEM layout, AddMultPA) spilled 12-96 B per
    // lane under that cap: two waves for them, no scratch (profiles/r2/d5_spill_probe.txt: BP4 p=4 320 -> 274 us,
@@ -1327,6 +1330,9 @@ static int launch_apply(int64_t ne, const double *B, const double *G, const doub
       }
       MFA_VARIANT(0, 1) MFA_VARIANT(2, 0) MFA_VARIANT(2, 1) MFA_VARIANT(3, 0) MFA_VARIANT(3, 1)
       MFA_VARIANT(0, 2) MFA_VARIANT(2, 2) MFA_VARIANT(3, 2)
+#ifdef MFA_DEEP_RING          // tuning builds: deeper rings (the table's RB level only)
+      MFA_VARIANT(4, 1) MFA_VARIANT(4, 2)
+#endif
 #undef MFA_VARIANT
    }
    const int mode = apply_mode(KIND, D, Q);   // 0 one batch per workgroup, 1 persistent/contiguous, 2 persistent/round-robin
