@@ -62,9 +62,10 @@ constexpr int minw_for(int KIND, int D, int PF = 0, int RB = 1, bool VEC = false
 constexpr bool stage_store_for(int KIND, int D, int Q)
 {
    if (MFA_STAGE_STORE >= 0) { return MFA_STAGE_STORE != 0; }
-   if (KIND == 0) { return D <= 8; }
-   if (Q == D) { return D >= 5 && D <= 7; }     // ((8,8) with its round-3 schedule -- whole columns, one batch per workgroup: direct stores 1-2 % faster)
-   return D != 4 && D != 8;
+   // Re-measured on the one-trip kernels (staged_stores_ab.txt, end; whole apply): every shape that had lost with the looping
+   // form gains now that the copy-out has registers -- (4,5) +2.3 %, (3,3) +3.8 %, (8,9) +1.5 % (it was 0.466 ms against 0.279
+   // with the loop), (9,9) +4 %, mass (9,10) +4..6 %, (4,4) +0.3 % -- except (8,8): -1.2 %
+   return !(KIND == 1 && D == 8 && Q == 8);
 }
 
 // KIND: 0 mass, 1 diffusion.  GATHER: x is an L-vector read through gmap (entries < 0 read
